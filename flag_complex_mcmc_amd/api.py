@@ -1,0 +1,337 @@
+"""Host-side mirror of the reference's interface for the hot path.
+
+Names, argument meaning and error behaviour follow the reference crate
+`directed-scm` (reference src/lib.rs, src/io.rs, src/bin/sample.rs) so a user
+of the reference finds the same objects here:
+
+    Graph                 flag_complex::Graph surface
+    Bounds                src/lib.rs:113-161
+    MCMCSampler           src/lib.rs:163-198 -- here a *batch* of independent
+                          chains on one GPU (one persistent workgroup each)
+    initialize_new_sampler  src/bin/sample.rs:80-105
+    read_flag_file / save_flag_file / BitOutput   src/io.rs:18-48,128-212
+
+Everything computes through libfcm.so (HIP); nothing here re-implements it.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import CBounds, CSamplerConfig, CSamplerInfo, FcmError, check, lib, u32p, u64p, i32p
+
+MOVE_DISTRIBUTION_SIMPLE = (0.5, 0.5, 0.0, 0.0)  # src/bin/sample.rs:16
+MOVE_DISTRIBUTION = (0.1, 0.1, 0.6, 0.2)         # src/bin/sample.rs:17 (clique moves: not built yet)
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(u32p)
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(u64p)
+
+
+class Graph:
+    """Directed graph without loops; adjacency as out-row bitmaps."""
+
+    def __init__(self, _h):
+        self._h = _h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().fcm_graph_destroy(h)
+
+    @classmethod
+    def new_disconnected(cls, nnodes):
+        h = C.c_void_p()
+        check(lib().fcm_graph_new_disconnected(nnodes, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_edges(cls, nnodes, edges):
+        e, ep = _u32(np.asarray(edges, dtype=np.uint32).reshape(-1, 2))
+        h = C.c_void_p()
+        check(lib().fcm_graph_from_edges(nnodes, len(e), ep, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_adjacency(cls, adj):
+        adj = np.asarray(adj)
+        return cls.from_edges(adj.shape[0], np.argwhere(adj != 0))
+
+    def clone(self):
+        h = C.c_void_p()
+        check(lib().fcm_graph_clone(self._h, C.byref(h)))
+        return Graph(h)
+
+    def nnodes(self):
+        return int(lib().fcm_graph_nnodes(self._h))
+
+    def nedges(self):
+        return int(lib().fcm_graph_nedges(self._h))
+
+    def has_edge(self, a, b):
+        return bool(lib().fcm_graph_has_edge(self._h, a, b))
+
+    def set_edge(self, a, b, present):
+        check(lib().fcm_graph_set_edge(self._h, a, b, int(bool(present))))
+
+    def add_edge(self, a, b):
+        check(lib().fcm_graph_add_edge(self._h, a, b))
+
+    def remove_edge(self, a, b):
+        check(lib().fcm_graph_remove_edge(self._h, a, b))
+
+    def edges(self):
+        m = C.c_uint64(0)
+        check(lib().fcm_graph_edges(self._h, None, 0, C.byref(m)))
+        out = np.zeros((max(m.value, 1), 2), np.uint32)
+        check(lib().fcm_graph_edges(self._h, out.ctypes.data_as(u32p), m.value, C.byref(m)))
+        return out[: m.value]
+
+    def undirected_edges(self):
+        m = C.c_uint64(0)
+        check(lib().fcm_graph_undirected_edges(self._h, None, 0, C.byref(m)))
+        out = np.zeros((max(m.value, 1), 2), np.uint32)
+        check(lib().fcm_graph_undirected_edges(self._h, out.ctypes.data_as(u32p), m.value, C.byref(m)))
+        return out[: m.value]
+
+    def flagser_count(self, device=0):
+        """Directed-flag-complex cell counts, on the GPU."""
+        out = np.zeros(_ffi.MAX_COUNTS, np.uint64)
+        ln = C.c_int(0)
+        check(lib().fcm_graph_flagser_count(self._h, device, out.ctypes.data_as(u64p), len(out), C.byref(ln)))
+        return [int(x) for x in out[: ln.value]]
+
+
+def count_unweighted(nvertices, edges):
+    """The reference's legacy wrapper (src/flagser.rs:13-21) over the C symbol
+    `flagser_count_unweighted`, here exported by libfcm.so."""
+    e, ep = _u32(np.asarray(edges, dtype=np.uint32).reshape(-1, 2))
+    n = C.c_size_t(0)
+    p = lib().flagser_count_unweighted(nvertices, len(e), ep, C.byref(n))
+    if not p:
+        raise FcmError(-1, lib().fcm_last_error().decode())
+    res = [int(x) for x in C.cast(p, u64p)[: n.value]]
+    lib()._free(p)
+    return res
+
+
+def read_flag_file(fname):
+    h = C.c_void_p()
+    check(lib().fcm_read_flag_file(os.fsencode(fname), C.byref(h)))
+    return Graph(h)
+
+
+def save_flag_file(fname, graph):
+    check(lib().fcm_save_flag_file(os.fsencode(fname), graph._h))
+
+
+class Bounds:
+    """`Bounds { flag_count_min, flag_count_max }` (src/lib.rs:113-117)."""
+
+    def __init__(self, flag_count_min, flag_count_max):
+        self.flag_count_min = [int(x) for x in flag_count_min]
+        self.flag_count_max = [int(x) for x in flag_count_max]
+
+    def _c(self):
+        b = CBounds()
+        for i, v in enumerate(self.flag_count_min):
+            b.flag_count_min[i] = v
+        for i, v in enumerate(self.flag_count_max):
+            b.flag_count_max[i] = v
+        b.min_len, b.max_len = len(self.flag_count_min), len(self.flag_count_max)
+        return b
+
+    @classmethod
+    def _from_c(cls, b):
+        return cls([b.flag_count_min[i] for i in range(b.min_len)], [b.flag_count_max[i] for i in range(b.max_len)])
+
+    @classmethod
+    def target(cls, flag_count, target_relaxation):
+        """src/bin/sample.rs:89-95"""
+        fc, fp = _u64(flag_count)
+        b = CBounds()
+        check(lib().fcm_target_bounds(fp, len(fc), target_relaxation, C.byref(b)))
+        return cls._from_c(b)
+
+    @classmethod
+    def calculate(cls, graph, flag_count, target_bounds, device=0, return_ncliques=False):
+        """Bounds::calculate (src/lib.rs:119-156)."""
+        fc, fp = _u64(flag_count)
+        out = CBounds()
+        t = target_bounds._c()
+        ncl = np.zeros(_ffi.MAX_COUNTS + 1, np.uint64)
+        nl = C.c_int(0)
+        check(lib().fcm_bounds_calculate(graph._h, fp, len(fc), C.byref(t), device, C.byref(out),
+                                         ncl.ctypes.data_as(u64p), C.byref(nl)))
+        b = cls._from_c(out)
+        return (b, [int(x) for x in ncl[: nl.value]]) if return_ncliques else b
+
+    def check(self, flag_count):
+        fc, fp = _u64(flag_count)
+        c = self._c()
+        return bool(lib().fcm_bounds_check(C.byref(c), fp, len(fc)))
+
+    def __repr__(self):
+        return "Bounds(min=%r, max=%r)" % (self.flag_count_min, self.flag_count_max)
+
+
+def default_sample_distance(nedges):
+    return int(lib().fcm_default_sample_distance(nedges))
+
+
+class MCMCSampler:
+    """A batch of independent chains of the reference's MCMCSampler on one GPU.
+
+    Chain i draws from the Philox stream (seed, first_chain_id + i), so a chain's
+    trajectory does not depend on how chains are split over handles or GPUs.
+    """
+
+    def __init__(self, graph, bounds, n_chains=1, seed=0, move_weights=MOVE_DISTRIBUTION_SIMPLE,
+                 sample_distance=0, dim_cap=0, device=0, first_chain_id=0):
+        cfg = CSamplerConfig()
+        cfg.n_chains, cfg.first_chain_id, cfg.seed = n_chains, first_chain_id, seed
+        for i in range(4):
+            cfg.move_weights[i] = move_weights[i]
+        cfg.sample_distance, cfg.dim_cap, cfg.device = sample_distance, dim_cap, device
+        h = C.c_void_p()
+        check(lib().fcm_sampler_create(graph._h, C.byref(bounds._c()), C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.n_chains = n_chains
+        self.bounds = bounds
+        self.ncounts = int(lib().fcm_sampler_ncounts(h))
+        self.sample_distance = int(lib().fcm_sampler_sample_distance(h))
+        info = CSamplerInfo()
+        check(lib().fcm_sampler_get_info(h, C.byref(info)))
+        self.info = {f: getattr(info, f) for f, _ in CSamplerInfo._fields_}
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().fcm_sampler_destroy(h)
+
+    def set_stream(self, hip_stream):
+        check(lib().fcm_sampler_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def step(self, n_proposals, sync=True):
+        check(lib().fcm_sampler_step(self._h, n_proposals))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        check(lib().fcm_sampler_sync(self._h))
+
+    def next(self):
+        """MCMCSampler::next: sample_distance proposals on every chain."""
+        check(lib().fcm_sampler_next(self._h))
+        return self
+
+    def last_step_ms(self):
+        ms = C.c_float(0)
+        check(lib().fcm_sampler_last_step_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def flag_counts(self, with_len=False):
+        out = np.zeros((self.n_chains, self.ncounts), np.uint64)
+        ln = np.zeros(self.n_chains, np.int32)
+        check(lib().fcm_sampler_get_counts(self._h, out.ctypes.data_as(u64p), ln.ctypes.data_as(i32p)))
+        return (out, ln) if with_len else out
+
+    def flag_count(self, chain=0):
+        """The chain's `state.flag_count` as the reference would print it."""
+        out, ln = self.flag_counts(with_len=True)
+        return [int(x) for x in out[chain, : ln[chain]]]
+
+    def stats(self):
+        out = np.zeros((self.n_chains, _ffi.NSTATS), np.uint64)
+        check(lib().fcm_sampler_get_stats(self._h, out.ctypes.data_as(u64p)))
+        return {name: out[:, i].copy() for i, name in enumerate(_ffi.STAT_NAMES)}
+
+    @property
+    def sampled(self):
+        return self.stats()["sampled"]
+
+    @property
+    def accepted(self):
+        return self.stats()["accepted"]
+
+    def acceptance_ratio(self):
+        st = self.stats()
+        return st["accepted"].astype(np.float64) / st["sampled"].astype(np.float64)
+
+    def edges(self, chain=0):
+        m = C.c_uint64(0)
+        check(lib().fcm_sampler_get_edges(self._h, chain, None, 0, C.byref(m)))
+        out = np.zeros((max(m.value, 1), 2), np.uint32)
+        check(lib().fcm_sampler_get_edges(self._h, chain, out.ctypes.data_as(u32p), m.value, C.byref(m)))
+        return out[: m.value]
+
+    def graph(self, chain=0):
+        return Graph.from_edges(self.info["n"], self.edges(chain))
+
+    def edgebits(self, chain=0):
+        n = C.c_uint64(0)
+        check(lib().fcm_sampler_get_edgebits(self._h, chain, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint8)
+        check(lib().fcm_sampler_get_edgebits(self._h, chain, out.ctypes.data_as(C.POINTER(C.c_uint8)), n.value, C.byref(n)))
+        return out[: n.value]
+
+    def double_slots(self, chain=0):
+        n = C.c_uint64(0)
+        check(lib().fcm_sampler_get_double_slots(self._h, chain, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint32)
+        check(lib().fcm_sampler_get_double_slots(self._h, chain, out.ctypes.data_as(u32p), n.value, C.byref(n)))
+        return out[: n.value]
+
+
+def initialize_new_sampler(input, target_relaxation=0.01, seed=0, sample_distance=0, simple=True,
+                           n_chains=1, device=0, dim_cap=0, first_chain_id=0):
+    """initialize_new_sampler (src/bin/sample.rs:80-105) for a batch of chains."""
+    g = input if isinstance(input, Graph) else read_flag_file(input)
+    flag_count = g.flagser_count(device)                       # State::new, src/lib.rs:51
+    target = Bounds.target(flag_count, target_relaxation)      # sample.rs:89-95
+    bounds = Bounds.calculate(g, flag_count, target, device)   # sample.rs:96-100
+    weights = MOVE_DISTRIBUTION_SIMPLE if simple else MOVE_DISTRIBUTION
+    return MCMCSampler(g, bounds, n_chains=n_chains, seed=seed, move_weights=weights,
+                       sample_distance=sample_distance, dim_cap=dim_cap, device=device,
+                       first_chain_id=first_chain_id)
+
+
+class BitOutput:
+    """`io::BitOutput` (src/io.rs:128-212): <dir>/graph.flag plus N.edgebits
+    files, each a run of fixed-size records (2 bits per adjacent pair)."""
+
+    def __init__(self, graph, dir):
+        os.makedirs(dir, exist_ok=True)
+        save_flag_file(os.path.join(dir, "graph.flag"), graph)
+        nslots = 2 * len(graph.undirected_edges())
+        if nslots // 8 == 0:
+            # the reference divides by zero here (src/io.rs:161)
+            raise FcmError(_ffi.ERR_PANIC, "fewer than 8 edge slots: reference BitOutput::new divides by zero")
+        self.chunk_size = max(2_000_000_000 // (nslots // 8), 1)
+        self.index_in_file = 0
+        self.index_in_dir = 0
+        self.current_file = None
+        self.dir = dir
+
+    def save(self, sampler, chain=0):
+        if self.index_in_file == 0:
+            self.current_file = open(os.path.join(self.dir, "%d.edgebits" % self.index_in_dir), "wb")
+        self.current_file.write(sampler.edgebits(chain).tobytes())
+        self.index_in_file += 1
+        if self.index_in_file == self.chunk_size:
+            self.current_file.close()
+            self.current_file = None
+            self.index_in_file = 0
+            self.index_in_dir += 1
+
+    def flush(self):
+        if self.current_file:
+            self.current_file.flush()

@@ -1,0 +1,58 @@
+// fcm_device.hpp — structs shared by the host code (fcm_host.cpp) and the
+// gfx950 kernels (fcm_kernels.hip).
+#pragma once
+#include <stdint.h>
+
+#define FCM_DEV_MAX_COUNTS 16
+#define FCM_DEV_NSTATS 8
+#define FCM_MAX_SUB 32           // philox blocks (2 candidates each) tried for the single edge of a double-edge move
+#define FCM_LAUNCH_CHUNK (1u << 16)  // proposals per chain per kernel launch
+
+// One entry per undirected edge e of pr(G), ascending (big, small):
+// the endpoints and the CSR slice of its static common neighbourhood
+// (reference State::edge_neighborhood, src/lib.rs:32, built at :331-356).
+struct FcmEdgeEntry {
+    uint32_t big, small, nb_off, k;
+};
+
+// HBM layout (DESIGN.md "Data layout"):
+//   rows  [n_chains][n][stride32] u32   out-row bitmaps, one chain after another; row = 128-B multiple
+//   dbl   [n_chains][dbl_stride]  u32   reciprocal-pair slot list (undirected edge ids)
+//   counts[n_chains][16]          u64   flag_count per chain
+//   stats [n_chains][8]           u64   FCM_STAT_* counters
+struct FcmStepParams {
+    const FcmEdgeEntry *etab;  // [U]
+    const uint32_t *nb;        // concatenated neighbour lists
+    uint32_t *rows;
+    uint32_t *dbl;
+    uint64_t *counts;
+    uint64_t *stats;
+    uint64_t bmin[FCM_DEV_MAX_COUNTS];
+    uint64_t bmax[FCM_DEV_MAX_COUNTS];
+    uint64_t cum0, cum1;       // move thresholds scaled to 2^32: flip if w0<cum0, double-move if w0<cum1
+    uint64_t seed;
+    uint64_t nprop;            // proposals to run in this launch
+    uint64_t rows_per_chain;   // n * stride32 (u32 words)
+    uint32_t n, stride32, U, D, dbl_stride, first_chain, nchains;
+    int32_t ncounts;           // tracked count entries NC (<= 16)
+};
+
+struct FcmCountParams {
+    const uint32_t *rows;      // [n][stride32] out-row bitmap of the graph to count
+    const uint32_t *edges;     // [m][2] directed edges (from,to)
+    uint64_t m;
+    uint64_t *counts;          // [16], entries 2.. accumulated with atomics
+    uint32_t *flags;           // [0] != 0: local set > 64; [1] != 0: dimension > 15 present
+    uint32_t n, stride32;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// launchers implemented in fcm_kernels.hip; `stream` is a hipStream_t
+int fcm_launch_step(const FcmStepParams *p, int maxt_variant, void *stream);
+int fcm_launch_count(const FcmCountParams *p, void *stream);
+int fcm_launch_broadcast_rows(uint32_t *rows, const uint32_t *base, uint64_t words_per_chain, uint32_t nchains, void *stream);
+#ifdef __cplusplus
+}
+#endif

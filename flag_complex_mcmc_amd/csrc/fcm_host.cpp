@@ -1,0 +1,904 @@
+// fcm_host.cpp — host side of libfcm.so: the C ABI declared in include/fcm.h.
+//
+// Holds what the reference keeps on the host around its hot loop: the Graph
+// surface, .flag I/O (src/io.rs:18-48), Bounds
+// (src/lib.rs:113-161, src/util.rs:53-105), the static neighbourhood table
+// (src/lib.rs:331-356) and sampler construction (src/lib.rs:38-58,
+// src/bin/sample.rs:87-104).  All counting and all MCMC stepping is done by
+// the HIP kernels in fcm_kernels.hip; there is no CPU fallback for either.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/fcm.h"
+#include "fcm_device.hpp"
+
+static_assert(FCM_MAX_COUNTS == FCM_DEV_MAX_COUNTS, "count vector width");
+static_assert(FCM_NSTATS == FCM_DEV_NSTATS, "stats width");
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) return fail(FCM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" const char *fcm_last_error(void) { return g_err; }
+extern "C" const char *fcm_version(void) { return "fcm-amd 0.1 (gfx950)"; }
+
+extern "C" int fcm_device_count(int *count)
+{
+    if (!count) return fail(FCM_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *count = n;
+    return FCM_OK;
+}
+
+static int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(FCM_ERR_NO_DEVICE, "no HIP device available (%s); libfcm has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return fail(FCM_ERR_NO_DEVICE, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return FCM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Graph
+// ---------------------------------------------------------------------------
+struct fcm_graph {
+    uint32_t n = 0;
+    uint32_t stride32 = 32;            // u32 words per row, multiple of 32 (128 B)
+    std::vector<uint32_t> rows;        // n * stride32, out-row bitmaps
+    uint64_t m = 0;                    // directed edges
+
+    bool has(uint32_t a, uint32_t b) const { return (rows[(size_t)a * stride32 + (b >> 5)] >> (b & 31)) & 1u; }
+    void set(uint32_t a, uint32_t b, bool present)
+    {
+        uint32_t &w = rows[(size_t)a * stride32 + (b >> 5)];
+        const uint32_t bit = 1u << (b & 31);
+        if (present) { if (!(w & bit)) { w |= bit; ++m; } }
+        else { if (w & bit) { w &= ~bit; --m; } }
+    }
+};
+
+static uint32_t stride_for(uint32_t n)
+{
+    uint32_t w = (n + 31) / 32;
+    w = (w + 31) / 32 * 32;
+    return w ? w : 32;
+}
+
+extern "C" int fcm_graph_new_disconnected(uint32_t nnodes, fcm_graph **out)
+{
+    if (!out) return fail(FCM_ERR_INVALID, "out is NULL");
+    fcm_graph *g = new (std::nothrow) fcm_graph;
+    if (!g) return fail(FCM_ERR_NOMEM, "out of memory");
+    g->n = nnodes;
+    g->stride32 = stride_for(nnodes);
+    try { g->rows.assign((size_t)nnodes * g->stride32, 0u); }
+    catch (...) { delete g; return fail(FCM_ERR_NOMEM, "out of memory for %u x %u bitmap", nnodes, nnodes); }
+    *out = g;
+    return FCM_OK;
+}
+
+extern "C" int fcm_graph_from_edges(uint32_t nnodes, uint64_t nedges, const fcm_node *edges, fcm_graph **out)
+{
+    if (nedges && !edges) return fail(FCM_ERR_INVALID, "edges is NULL");
+    fcm_graph *g = nullptr;
+    int rc = fcm_graph_new_disconnected(nnodes, &g);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < nedges; ++i) {
+        const uint32_t a = edges[2 * i], b = edges[2 * i + 1];
+        if (a >= nnodes || b >= nnodes) { delete g; return fail(FCM_ERR_INVALID, "edge %llu = (%u,%u) out of range", (unsigned long long)i, a, b); }
+        if (a == b) continue;  // a flag complex has no loops
+        g->set(a, b, true);
+    }
+    *out = g;
+    return FCM_OK;
+}
+
+extern "C" int fcm_graph_clone(const fcm_graph *g, fcm_graph **out)
+{
+    if (!g || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    fcm_graph *h = new (std::nothrow) fcm_graph(*g);
+    if (!h) return fail(FCM_ERR_NOMEM, "out of memory");
+    *out = h;
+    return FCM_OK;
+}
+
+extern "C" void fcm_graph_destroy(fcm_graph *g) { delete g; }
+extern "C" uint32_t fcm_graph_nnodes(const fcm_graph *g) { return g ? g->n : 0; }
+extern "C" uint64_t fcm_graph_nedges(const fcm_graph *g) { return g ? g->m : 0; }
+
+extern "C" int fcm_graph_has_edge(const fcm_graph *g, fcm_node a, fcm_node b)
+{
+    if (!g || a >= g->n || b >= g->n) return 0;
+    return g->has(a, b) ? 1 : 0;
+}
+
+extern "C" int fcm_graph_set_edge(fcm_graph *g, fcm_node a, fcm_node b, int present)
+{
+    if (!g) return fail(FCM_ERR_INVALID, "graph is NULL");
+    if (a >= g->n || b >= g->n) return fail(FCM_ERR_INVALID, "edge (%u,%u) out of range", a, b);
+    if (a == b) return fail(FCM_ERR_INVALID, "self-loop (%u,%u)", a, b);
+    g->set(a, b, present != 0);
+    return FCM_OK;
+}
+extern "C" int fcm_graph_add_edge(fcm_graph *g, fcm_node a, fcm_node b) { return fcm_graph_set_edge(g, a, b, 1); }
+extern "C" int fcm_graph_remove_edge(fcm_graph *g, fcm_node a, fcm_node b) { return fcm_graph_set_edge(g, a, b, 0); }
+
+template <class F>
+static void for_each_edge(const fcm_graph &g, F f)
+{
+    const uint32_t nw = (g.n + 31) / 32;
+    for (uint32_t a = 0; a < g.n; ++a) {
+        const uint32_t *row = &g.rows[(size_t)a * g.stride32];
+        for (uint32_t w = 0; w < nw; ++w) {
+            uint32_t x = row[w];
+            while (x) {
+                const uint32_t b = w * 32 + (uint32_t)__builtin_ctz(x);
+                x &= x - 1;
+                f(a, b);
+            }
+        }
+    }
+}
+
+extern "C" int fcm_graph_edges(const fcm_graph *g, fcm_node *out, uint64_t cap, uint64_t *m)
+{
+    if (!g) return fail(FCM_ERR_INVALID, "graph is NULL");
+    uint64_t i = 0;
+    for_each_edge(*g, [&](uint32_t a, uint32_t b) {
+        if (out && i < cap) { out[2 * i] = a; out[2 * i + 1] = b; }
+        ++i;
+    });
+    if (m) *m = i;
+    return FCM_OK;
+}
+
+// undirected adjacency bitmap: und[a] = out[a] | in[a]
+static std::vector<uint32_t> undirected_bitmap(const fcm_graph &g)
+{
+    std::vector<uint32_t> und(g.rows);
+    for_each_edge(g, [&](uint32_t a, uint32_t b) { und[(size_t)b * g.stride32 + (a >> 5)] |= 1u << (a & 31); });
+    return und;
+}
+
+// undirected_edges(): [a,b] with a > b, ascending (a,b) (src/lib.rs:341,344)
+static void undirected_edge_list(const fcm_graph &g, const std::vector<uint32_t> &und, std::vector<uint32_t> &out)
+{
+    out.clear();
+    for (uint32_t a = 0; a < g.n; ++a) {
+        const uint32_t *row = &und[(size_t)a * g.stride32];
+        const uint32_t nw = a / 32 + 1;
+        for (uint32_t w = 0; w < nw; ++w) {
+            uint32_t x = row[w];
+            while (x) {
+                const uint32_t b = w * 32 + (uint32_t)__builtin_ctz(x);
+                x &= x - 1;
+                if (b < a) { out.push_back(a); out.push_back(b); }
+            }
+        }
+    }
+}
+
+extern "C" int fcm_graph_undirected_edges(const fcm_graph *g, fcm_node *out, uint64_t cap, uint64_t *m)
+{
+    if (!g) return fail(FCM_ERR_INVALID, "graph is NULL");
+    std::vector<uint32_t> und = undirected_bitmap(*g), ue;
+    undirected_edge_list(*g, und, ue);
+    const uint64_t u = ue.size() / 2;
+    if (out) memcpy(out, ue.data(), sizeof(uint32_t) * 2 * (size_t)std::min<uint64_t>(u, cap));
+    if (m) *m = u;
+    return FCM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device counting (flagser_count)
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) { p = nullptr; return fail(FCM_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        return FCM_OK;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// counts[0..15]; *len = 1 + highest non-zero dimension.  `rows`/`edges` host.
+static int device_count(const uint32_t *rows, uint32_t n, uint32_t stride32, const std::vector<uint32_t> &edges,
+                        int device, uint64_t counts[FCM_MAX_COUNTS], int *len)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    memset(counts, 0, sizeof(uint64_t) * FCM_MAX_COUNTS);
+    const uint64_t m = edges.size() / 2;
+    counts[0] = n;
+    counts[1] = m;
+    if (m > 0) {
+        DevBuf d_rows, d_edges, d_counts, d_flags;
+        const size_t row_bytes = (size_t)n * stride32 * sizeof(uint32_t);
+        if ((rc = d_rows.alloc(row_bytes))) return rc;
+        if ((rc = d_edges.alloc(edges.size() * sizeof(uint32_t)))) return rc;
+        if ((rc = d_counts.alloc(sizeof(uint64_t) * FCM_MAX_COUNTS))) return rc;
+        if ((rc = d_flags.alloc(sizeof(uint32_t) * 2))) return rc;
+        HIP_TRY(hipMemcpy(d_rows.p, rows, row_bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_edges.p, edges.data(), edges.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(d_counts.p, 0, sizeof(uint64_t) * FCM_MAX_COUNTS));
+        HIP_TRY(hipMemset(d_flags.p, 0, sizeof(uint32_t) * 2));
+        FcmCountParams p;
+        p.rows = d_rows.as<uint32_t>();
+        p.edges = d_edges.as<uint32_t>();
+        p.m = m;
+        p.counts = d_counts.as<uint64_t>();
+        p.flags = d_flags.as<uint32_t>();
+        p.n = n;
+        p.stride32 = stride32;
+        int lrc = fcm_launch_count(&p, nullptr);
+        if (lrc) return fail(FCM_ERR_HIP, "count kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+        HIP_TRY(hipDeviceSynchronize());
+        uint64_t dc[FCM_MAX_COUNTS];
+        uint32_t flags[2];
+        HIP_TRY(hipMemcpy(dc, d_counts.p, sizeof dc, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost));
+        if (flags[0])
+            return fail(FCM_ERR_UNSUPPORTED, "an edge has more than %d common out-neighbours; not supported by this build", FCM_MAX_LOCAL);
+        if (flags[1])
+            return fail(FCM_ERR_UNSUPPORTED, "graph holds simplices of dimension > %d", FCM_MAX_COUNTS - 1);
+        for (int d = 2; d < FCM_MAX_COUNTS; ++d) counts[d] = dc[d];
+    }
+    int l = 0;
+    for (int d = 0; d < FCM_MAX_COUNTS; ++d) if (counts[d]) l = d + 1;
+    *len = l;
+    return FCM_OK;
+}
+
+static void edge_list(const fcm_graph &g, std::vector<uint32_t> &edges)
+{
+    edges.clear();
+    edges.reserve((size_t)g.m * 2);
+    for_each_edge(g, [&](uint32_t a, uint32_t b) { edges.push_back(a); edges.push_back(b); });
+}
+
+extern "C" int fcm_graph_flagser_count(const fcm_graph *g, int device, uint64_t *counts, int cap, int *len)
+{
+    if (!g || !counts || !len) return fail(FCM_ERR_INVALID, "NULL argument");
+    std::vector<uint32_t> edges;
+    edge_list(*g, edges);
+    uint64_t c[FCM_MAX_COUNTS];
+    int l = 0;
+    int rc = device_count(g->rows.data(), g->n, g->stride32, edges, device, c, &l);
+    if (rc) return rc;
+    if (l > cap) return fail(FCM_ERR_INVALID, "counts buffer too small: need %d, have %d", l, cap);
+    for (int d = 0; d < l; ++d) counts[d] = c[d];
+    *len = l;
+    return FCM_OK;
+}
+
+static int default_device()
+{
+    const char *e = getenv("FCM_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+// Legacy symbol, src/flagser.rs:7-10.
+extern "C" size_t *flagser_count_unweighted(size_t nvertices, size_t nedges, const fcm_node (*edges)[2], size_t *res_size)
+{
+    if (res_size) *res_size = 0;
+    if (!res_size || nvertices > 0xFFFFFFFFull) { fail(FCM_ERR_INVALID, "bad arguments"); return nullptr; }
+    fcm_graph *g = nullptr;
+    if (fcm_graph_from_edges((uint32_t)nvertices, nedges, (const fcm_node *)edges, &g)) return nullptr;
+    uint64_t c[FCM_MAX_COUNTS];
+    int len = 0;
+    int rc = fcm_graph_flagser_count(g, default_device(), c, FCM_MAX_COUNTS, &len);
+    fcm_graph_destroy(g);
+    if (rc) return nullptr;
+    size_t *res = (size_t *)malloc(sizeof(size_t) * (size_t)(len ? len : 1));
+    if (!res) { fail(FCM_ERR_NOMEM, "out of memory"); return nullptr; }
+    for (int d = 0; d < len; ++d) res[d] = (size_t)c[d];
+    *res_size = (size_t)len;
+    return res;
+}
+
+// ---------------------------------------------------------------------------
+// .flag I/O (src/io.rs:18-48)
+// ---------------------------------------------------------------------------
+static void split_spaces(const std::string &line, std::vector<std::string> &tok)
+{
+    tok.clear();
+    size_t i = 0;
+    while (i < line.size()) {
+        while (i < line.size() && line[i] == ' ') ++i;
+        size_t j = i;
+        while (j < line.size() && line[j] != ' ') ++j;
+        if (j > i) tok.emplace_back(line, i, j - i);
+        i = j;
+    }
+}
+
+extern "C" int fcm_read_flag_file(const char *path, fcm_graph **out)
+{
+    if (!path || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return fail(FCM_ERR_IO, "could not find .flag input file %s", path);
+    std::string line;
+    std::vector<std::string> tok;
+    fcm_graph *g = nullptr;
+    int lineno = 0;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (lineno == 1) {                       // vertex line: count tokens (io.rs:25)
+            split_spaces(line, tok);
+            int rc = fcm_graph_new_disconnected((uint32_t)tok.size(), &g);
+            if (rc) return rc;
+        } else if (lineno >= 3) {                // edge lines (io.rs:28-32)
+            if (!g) return fail(FCM_ERR_IO, "%s: truncated header", path);
+            split_spaces(line, tok);
+            if (tok.size() >= 2) {
+                char *e1 = nullptr, *e2 = nullptr;
+                errno = 0;
+                const unsigned long long a = strtoull(tok[0].c_str(), &e1, 10), b = strtoull(tok[1].c_str(), &e2, 10);
+                if (errno || *e1 || *e2 || a >= g->n || b >= g->n) {
+                    delete g;
+                    return fail(FCM_ERR_IO, "%s:%d: bad edge line '%s'", path, lineno + 1, line.c_str());
+                }
+                if (a != b) g->set((uint32_t)a, (uint32_t)b, true);
+            }
+        }
+        ++lineno;
+    }
+    if (!g) return fail(FCM_ERR_IO, "%s: no vertex line", path);
+    *out = g;
+    return FCM_OK;
+}
+
+extern "C" int fcm_save_flag_file(const char *path, const fcm_graph *g)
+{
+    if (!path || !g) return fail(FCM_ERR_INVALID, "NULL argument");
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return fail(FCM_ERR_IO, "Unable to write file %s", path);
+    f << "dim 0:\n";
+    for (uint32_t i = 0; i < g->n; ++i) f << (i ? " 1" : "1");
+    f << "\ndim 1:\n";
+    for_each_edge(*g, [&](uint32_t a, uint32_t b) { f << a << ' ' << b << " 1\n"; });  // ascending = sort_unstable (io.rs:42)
+    if (!f) return fail(FCM_ERR_IO, "write to %s failed", path);
+    return FCM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Bounds (src/lib.rs:113-161; src/util.rs:53-105; src/bin/sample.rs:89-102)
+// ---------------------------------------------------------------------------
+static bool all_le(const uint64_t *a, int na, const uint64_t *b, int nb)  // util.rs:53-63, z = 0
+{
+    const int ml = std::max(na, nb);
+    for (int i = 0; i < ml; ++i) {
+        const uint64_t l = i < na ? a[i] : 0, r = i < nb ? b[i] : 0;
+        if (l > r) return false;
+    }
+    return true;
+}
+
+// util.rs:65-71: the loop is `1..x`, i.e. (x-1)!
+static uint64_t ref_factorial(uint64_t x)
+{
+    uint64_t r = 1;
+    for (uint64_t i = 1; i < x; ++i) r *= i;
+    return r;
+}
+
+// OEIS A058298, n!/(n-k), 1 <= k < n, by rows; first 64 terms (util.rs:98-105)
+static const std::vector<uint64_t> &a058298()
+{
+    static std::vector<uint64_t> t;
+    if (t.empty()) {
+        uint64_t fact = 1;
+        for (uint64_t n = 2; t.size() < 64; ++n) {
+            fact *= n;
+            for (uint64_t k = 1; k < n && t.size() < 64; ++k) t.push_back(fact / (n - k));
+        }
+    }
+    return t;
+}
+
+extern "C" int fcm_target_bounds(const uint64_t *flag_count, int len, double r, fcm_bounds *out)
+{
+    if (!flag_count || !out || len < 0 || len > FCM_MAX_COUNTS) return fail(FCM_ERR_INVALID, "bad arguments");
+    memset(out, 0, sizeof *out);
+    out->min_len = out->max_len = len;
+    for (int d = 0; d < len; ++d) {
+        if (d < 2) out->flag_count_min[d] = out->flag_count_max[d] = flag_count[d];
+        else {
+            out->flag_count_min[d] = (uint64_t)std::floor((double)flag_count[d] * (1. - r));
+            out->flag_count_max[d] = (uint64_t)std::floor((double)flag_count[d] * (1. + r));
+        }
+    }
+    return FCM_OK;
+}
+
+static int clique_counts(const fcm_graph &g, int device, uint64_t ncl[FCM_MAX_COUNTS], int *ncl_len, uint64_t *n_undirected)
+{
+    // normalized graph: edge big->small for every adjacent pair (lib.rs:125-129)
+    std::vector<uint32_t> und = undirected_bitmap(g), ue;
+    undirected_edge_list(g, und, ue);
+    std::vector<uint32_t> rows((size_t)g.n * g.stride32, 0u);
+    for (size_t e = 0; e < ue.size(); e += 2) rows[(size_t)ue[e] * g.stride32 + (ue[e + 1] >> 5)] |= 1u << (ue[e + 1] & 31);
+    if (n_undirected) *n_undirected = ue.size() / 2;
+    return device_count(rows.data(), g.n, g.stride32, ue, device, ncl, ncl_len);
+}
+
+extern "C" int fcm_bounds_calculate(const fcm_graph *g, const uint64_t *flag_count, int len, const fcm_bounds *target,
+                                    int device, fcm_bounds *out, uint64_t *ncliques, int *ncliques_len)
+{
+    if (!g || !flag_count || !target || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    if (len > FCM_MAX_COUNTS) return fail(FCM_ERR_INVALID, "len > %d", FCM_MAX_COUNTS);
+    uint64_t ncl[FCM_MAX_COUNTS];
+    int ncl_len = 0;
+    uint64_t U = 0;
+    int rc = clique_counts(*g, device, ncl, &ncl_len, &U);   // lib.rs:130
+    if (rc) return rc;
+    if (ncliques) { memset(ncliques, 0, sizeof(uint64_t) * (FCM_MAX_COUNTS + 1)); memcpy(ncliques, ncl, sizeof ncl); }
+    if (ncliques_len) *ncliques_len = ncl_len;
+    if (len < 2) return fail(FCM_ERR_PANIC, "reference indexes flag_count[1] (src/lib.rs:135)");
+    if (U == flag_count[1]) {  // SEO case, lib.rs:135-137
+        memset(out, 0, sizeof *out);
+        memcpy(out->flag_count_min, target->flag_count_min, sizeof out->flag_count_min);
+        out->min_len = target->min_len;
+        memcpy(out->flag_count_max, ncl, sizeof ncl);
+        out->max_len = ncl_len;
+        return FCM_OK;
+    }
+    *out = *target;
+    // calc_relax_de, util.rs:79-93
+    const std::vector<uint64_t> &A = a058298();
+    uint64_t relax_de[FCM_MAX_COUNTS];
+    for (int d = 0; d < len; ++d) {
+        size_t ind = 1;
+        uint64_t best = 0;
+        bool have = false;
+        for (;;) {
+            if (ind >= A.size()) return fail(FCM_ERR_PANIC, "calc_relax_de table overrun: count[%d]=%llu (src/util.rs:84)", d, (unsigned long long)flag_count[d]);
+            if (!(A[ind] < flag_count[d])) break;
+            const uint64_t lost = A[ind] - A[ind - 1];
+            if (!have || lost > best) { best = lost; have = true; }
+            ++ind;
+        }
+        relax_de[d] = std::min(have ? best : (uint64_t)1, ref_factorial((uint64_t)d + 1));
+    }
+    for (int d = 2; d < len; ++d) {
+        if (d >= out->max_len || d >= out->min_len) return fail(FCM_ERR_PANIC, "target bounds shorter than flag_count (src/lib.rs:148)");
+        const uint64_t nn = (uint64_t)len - 2, kk = (uint64_t)d - 1;    // binomial(len-2, d-1), lib.rs:144
+        if (kk > nn) return fail(FCM_ERR_PANIC, "binomial underflow (src/util.rs:76)");
+        const uint64_t f = ref_factorial(nn) / (ref_factorial(kk) * ref_factorial(nn - kk));
+        const uint64_t relax = relax_de[d] * f;
+        out->flag_count_max[d] = std::max(out->flag_count_min[d] + relax, out->flag_count_max[d]);   // :148
+        out->flag_count_min[d] = std::min(out->flag_count_max[d] - relax, out->flag_count_min[d]);   // :149
+    }
+    if (out->max_len < 3) return fail(FCM_ERR_PANIC, "flag_count_max[2] out of range (src/lib.rs:151)");
+    out->flag_count_max[2] = UINT64_MAX;                // :151
+    out->flag_count_max[out->max_len++] = 10;           // :152
+    return FCM_OK;
+}
+
+extern "C" int fcm_bounds_check(const fcm_bounds *b, const uint64_t *flag_count, int len)
+{
+    if (!b || !flag_count) return 0;
+    return all_le(b->flag_count_min, b->min_len, flag_count, len) && all_le(flag_count, len, b->flag_count_max, b->max_len);
+}
+
+extern "C" uint64_t fcm_default_sample_distance(uint64_t nedges)
+{
+    const double e = (double)nedges;
+    return (uint64_t)std::ceil(2. * e * std::log2(e));
+}
+
+// ---------------------------------------------------------------------------
+// Sampler
+// ---------------------------------------------------------------------------
+struct fcm_sampler {
+    int device = 0;
+    fcm_sampler_config cfg{};
+    fcm_sampler_info info{};
+    FcmStepParams params{};
+    int maxt_variant = 6;
+    uint32_t n = 0, stride32 = 0;
+    std::vector<uint32_t> ue;          // [U][2] big, small
+    // device buffers
+    DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+
+    ~fcm_sampler()
+    {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+};
+
+static void move_thresholds(const double w[4], uint64_t cum[4])
+{
+    const double total = w[0] + w[1] + w[2] + w[3];
+    double acc = 0;
+    for (int i = 0; i < 4; ++i) {
+        acc += w[i];
+        cum[i] = (uint64_t)std::floor(4294967296.0 * (acc / total));
+    }
+    int last = 0;
+    for (int i = 0; i < 4; ++i) if (w[i] > 0.0) last = i;
+    for (int i = last; i < 4; ++i) cum[i] = 4294967296ull;
+}
+
+extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, const fcm_sampler_config *cfg, fcm_sampler **out)
+{
+    if (!g || !bounds || !cfg || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    if (cfg->n_chains == 0) return fail(FCM_ERR_INVALID, "n_chains must be > 0");
+    for (int i = 0; i < 4; ++i)
+        if (!(cfg->move_weights[i] >= 0.0) || !std::isfinite(cfg->move_weights[i]))
+            return fail(FCM_ERR_INVALID, "move weight %d is negative or not finite", i);
+    if (cfg->move_weights[0] + cfg->move_weights[1] + cfg->move_weights[2] + cfg->move_weights[3] <= 0.0)
+        return fail(FCM_ERR_INVALID, "all move weights are zero");
+    if (cfg->move_weights[2] != 0.0 || cfg->move_weights[3] != 0.0)
+        return fail(FCM_ERR_UNSUPPORTED, "clique_permute / clique_swap moves are not built yet; use the --simple weights [w0,w1,0,0]");
+    if (bounds->min_len < 0 || bounds->min_len > FCM_MAX_COUNTS || bounds->max_len < 0 || bounds->max_len > FCM_MAX_COUNTS)
+        return fail(FCM_ERR_UNSUPPORTED, "bounds longer than %d entries", FCM_MAX_COUNTS);
+    int rc = use_device(cfg->device);
+    if (rc) return rc;
+
+    fcm_sampler *s = new (std::nothrow) fcm_sampler;
+    if (!s) return fail(FCM_ERR_NOMEM, "out of memory");
+    struct Guard { fcm_sampler *s; ~Guard() { delete s; } } guard{s};
+    s->device = cfg->device;
+    s->cfg = *cfg;
+    s->n = g->n;
+    s->stride32 = g->stride32;
+
+    // --- static tables: undirected edges and their common neighbourhoods ---
+    std::vector<uint32_t> und = undirected_bitmap(*g);
+    undirected_edge_list(*g, und, s->ue);
+    const uint64_t U = s->ue.size() / 2;
+    if (U >= 0xFFFFFFFFull) return fail(FCM_ERR_UNSUPPORTED, "too many undirected edges");
+    std::vector<FcmEdgeEntry> etab((size_t)U);
+    std::vector<uint32_t> nb;
+    std::vector<uint32_t> dbl0;
+    const uint32_t nw = (g->n + 31) / 32;
+    uint32_t kmax = 0;
+    uint64_t ksum = 0;
+    for (uint64_t e = 0; e < U; ++e) {
+        const uint32_t a = s->ue[2 * e], b = s->ue[2 * e + 1];
+        const uint32_t *ra = &und[(size_t)a * g->stride32], *rb = &und[(size_t)b * g->stride32];
+        if ((uint64_t)nb.size() > 0xFFFFFF00ull) return fail(FCM_ERR_UNSUPPORTED, "neighbourhood table exceeds 2^32 entries");
+        etab[e].big = a; etab[e].small = b; etab[e].nb_off = (uint32_t)nb.size();
+        uint32_t k = 0;
+        for (uint32_t w = 0; w < nw; ++w) {
+            uint32_t x = ra[w] & rb[w];
+            while (x) {
+                nb.push_back(w * 32 + (uint32_t)__builtin_ctz(x));
+                x &= x - 1;
+                ++k;
+            }
+        }
+        etab[e].k = k;
+        kmax = std::max(kmax, k);
+        ksum += k;
+        if (g->has(a, b) && g->has(b, a)) dbl0.push_back((uint32_t)e);
+    }
+    if (kmax + 2 > FCM_MAX_LOCAL)
+        return fail(FCM_ERR_UNSUPPORTED, "an edge has %u common neighbours; this build supports at most %d", kmax, FCM_MAX_LOCAL - 2);
+    const uint64_t D = dbl0.size();
+
+    // --- initial counts and the reachable dimension range ------------------
+    std::vector<uint32_t> edges;
+    edge_list(*g, edges);
+    uint64_t fc[FCM_MAX_COUNTS], ncl[FCM_MAX_COUNTS];
+    int fc_len = 0, ncl_len = 0;
+    if ((rc = device_count(g->rows.data(), g->n, g->stride32, edges, cfg->device, fc, &fc_len))) return rc;   // lib.rs:51
+    if ((rc = clique_counts(*g, cfg->device, ncl, &ncl_len, nullptr))) return rc;
+    int want = std::max(std::max(fc_len, ncl_len), std::max((int)bounds->min_len, (int)bounds->max_len));
+    want = std::max(want, 2);
+    int nc = want;
+    bool lossless = true;
+    if (cfg->dim_cap > 0 && cfg->dim_cap + 1 < want) { nc = cfg->dim_cap + 1; lossless = false; }
+    if (nc > FCM_MAX_COUNTS) return fail(FCM_ERR_UNSUPPORTED, "needs %d count entries, this build tracks at most %d; pass a dim_cap", nc, FCM_MAX_COUNTS);
+    nc = std::max(nc, 2);
+    s->maxt_variant = (nc - 2 <= 6) ? 6 : 14;
+
+    // --- device buffers -----------------------------------------------------
+    const uint64_t rows_per_chain = (uint64_t)g->n * g->stride32;
+    const uint32_t dbl_stride = (uint32_t)((D + 31) / 32 * 32);
+    const uint32_t C = cfg->n_chains;
+    if ((rc = s->d_etab.alloc(std::max<size_t>(1, etab.size()) * sizeof(FcmEdgeEntry)))) return rc;
+    if ((rc = s->d_nb.alloc((nb.size() + 64) * sizeof(uint32_t)))) return rc;
+    if ((rc = s->d_rows.alloc((size_t)C * rows_per_chain * sizeof(uint32_t)))) return rc;
+    if ((rc = s->d_dbl.alloc(std::max<size_t>(1, (size_t)C * dbl_stride) * sizeof(uint32_t)))) return rc;
+    if ((rc = s->d_counts.alloc((size_t)C * FCM_MAX_COUNTS * sizeof(uint64_t)))) return rc;
+    if ((rc = s->d_stats.alloc((size_t)C * FCM_NSTATS * sizeof(uint64_t)))) return rc;
+    if (!etab.empty()) HIP_TRY(hipMemcpy(s->d_etab.p, etab.data(), etab.size() * sizeof(FcmEdgeEntry), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(s->d_nb.p, 0, (nb.size() + 64) * sizeof(uint32_t)));
+    if (!nb.empty()) HIP_TRY(hipMemcpy(s->d_nb.p, nb.data(), nb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {
+        DevBuf d_base;
+        if ((rc = d_base.alloc(rows_per_chain * sizeof(uint32_t)))) return rc;
+        HIP_TRY(hipMemcpy(d_base.p, g->rows.data(), rows_per_chain * sizeof(uint32_t), hipMemcpyHostToDevice));
+        int lrc = fcm_launch_broadcast_rows(s->d_rows.as<uint32_t>(), d_base.as<uint32_t>(), rows_per_chain, C, nullptr);
+        if (lrc) return fail(FCM_ERR_HIP, "broadcast launch failed: %s", hipGetErrorString((hipError_t)lrc));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    {
+        std::vector<uint32_t> h((size_t)C * dbl_stride, 0u);
+        for (uint32_t c = 0; c < C; ++c) std::copy(dbl0.begin(), dbl0.end(), h.begin() + (size_t)c * dbl_stride);
+        if (!h.empty()) HIP_TRY(hipMemcpy(s->d_dbl.p, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::vector<uint64_t> hc((size_t)C * FCM_MAX_COUNTS, 0), hs((size_t)C * FCM_NSTATS, 0);
+        for (uint32_t c = 0; c < C; ++c) {
+            for (int d = 0; d < nc && d < FCM_MAX_COUNTS; ++d) hc[(size_t)c * FCM_MAX_COUNTS + d] = fc[d];
+            hs[(size_t)c * FCM_NSTATS + FCM_STAT_COUNT_LEN] = (uint64_t)std::min(fc_len, nc);
+        }
+        HIP_TRY(hipMemcpy(s->d_counts.p, hc.data(), hc.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_stats.p, hs.data(), hs.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipStreamCreate(&s->own_stream));
+    s->stream = s->own_stream;
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+
+    // --- kernel parameters ---------------------------------------------------
+    FcmStepParams &p = s->params;
+    memset(&p, 0, sizeof p);
+    p.etab = s->d_etab.as<FcmEdgeEntry>();
+    p.nb = s->d_nb.as<uint32_t>();
+    p.rows = s->d_rows.as<uint32_t>();
+    p.dbl = s->d_dbl.as<uint32_t>();
+    p.counts = s->d_counts.as<uint64_t>();
+    p.stats = s->d_stats.as<uint64_t>();
+    for (int d = 0; d < FCM_MAX_COUNTS; ++d) {
+        // zero padding of the shorter side, src/util.rs:53-57
+        p.bmin[d] = d < bounds->min_len ? bounds->flag_count_min[d] : 0;
+        p.bmax[d] = d < bounds->max_len ? bounds->flag_count_max[d] : 0;
+    }
+    uint64_t cum[4];
+    move_thresholds(cfg->move_weights, cum);
+    p.cum0 = cum[0];
+    p.cum1 = cum[1];
+    p.seed = cfg->seed;
+    p.rows_per_chain = rows_per_chain;
+    p.n = g->n;
+    p.stride32 = g->stride32;
+    p.U = (uint32_t)U;
+    p.D = (uint32_t)D;
+    p.dbl_stride = dbl_stride;
+    p.first_chain = cfg->first_chain_id;
+    p.nchains = C;
+    p.ncounts = nc;
+
+    if (s->cfg.sample_distance == 0) s->cfg.sample_distance = fcm_default_sample_distance(fc[1]);  // sample.rs:102
+
+    fcm_sampler_info &I = s->info;
+    I.n = g->n;
+    I.row_words = g->stride32 / 2;
+    I.n_undirected = U;
+    I.n_double = D;
+    I.k_max = kmax;
+    I.k_mean = U ? (double)ksum / (double)U : 0.0;
+    I.bytes_per_chain = rows_per_chain * 4 + (uint64_t)dbl_stride * 4 + FCM_MAX_COUNTS * 8 + FCM_NSTATS * 8;
+    I.bytes_static = etab.size() * sizeof(FcmEdgeEntry) + nb.size() * 4;
+    I.ncounts = nc;
+    I.lossless = lossless ? 1 : 0;
+
+    guard.s = nullptr;
+    *out = s;
+    return FCM_OK;
+}
+
+extern "C" void fcm_sampler_destroy(fcm_sampler *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    delete s;
+}
+
+extern "C" int fcm_sampler_set_stream(fcm_sampler *s, void *hip_stream)
+{
+    if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
+    s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals)
+{
+    if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
+    int rc = use_device(s->device);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    uint64_t left = n_proposals;
+    while (left > 0) {
+        const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
+        s->params.nprop = chunk;
+        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->stream);
+        if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+        left -= chunk;
+    }
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    s->timed = true;
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_sync(fcm_sampler *s)
+{
+    if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
+    int rc = use_device(s->device);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_next(fcm_sampler *s)
+{
+    if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
+    int rc = fcm_sampler_step(s, s->cfg.sample_distance);
+    if (rc) return rc;
+    return fcm_sampler_sync(s);
+}
+
+extern "C" int fcm_sampler_last_step_ms(fcm_sampler *s, float *ms)
+{
+    if (!s || !ms) return fail(FCM_ERR_INVALID, "NULL argument");
+    if (!s->timed) return fail(FCM_ERR_INVALID, "no step has been launched");
+    int rc = use_device(s->device);
+    if (rc) return rc;
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_ncounts(const fcm_sampler *s) { return s ? s->params.ncounts : 0; }
+extern "C" uint64_t fcm_sampler_sample_distance(const fcm_sampler *s) { return s ? s->cfg.sample_distance : 0; }
+
+static int fetch_stats(fcm_sampler *s, std::vector<uint64_t> &hs)
+{
+    int rc = fcm_sampler_sync(s);
+    if (rc) return rc;
+    hs.resize((size_t)s->params.nchains * FCM_NSTATS);
+    HIP_TRY(hipMemcpy(hs.data(), s->d_stats.p, hs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < s->params.nchains; ++c) {
+        const uint64_t st = hs[(size_t)c * FCM_NSTATS + FCM_STAT_STATUS];
+        if (st) return fail(FCM_ERR_INTERNAL, "chain %u: device-side consistency check failed (status 0x%llx)", c, (unsigned long long)st);
+    }
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len)
+{
+    if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    std::vector<uint64_t> hs;
+    int rc = fetch_stats(s, hs);
+    if (rc) return rc;
+    const uint32_t C = s->params.nchains;
+    const int nc = s->params.ncounts;
+    std::vector<uint64_t> hc((size_t)C * FCM_MAX_COUNTS);
+    HIP_TRY(hipMemcpy(hc.data(), s->d_counts.p, hc.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < C; ++c) {
+        for (int d = 0; d < nc; ++d) out[(size_t)c * nc + d] = hc[(size_t)c * FCM_MAX_COUNTS + d];
+        if (count_len) count_len[c] = (int32_t)hs[(size_t)c * FCM_NSTATS + FCM_STAT_COUNT_LEN];
+    }
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out)
+{
+    if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    std::vector<uint64_t> hs;
+    int rc = fetch_stats(s, hs);
+    if (rc) return rc;
+    memcpy(out, hs.data(), hs.size() * sizeof(uint64_t));
+    return FCM_OK;
+}
+
+static int fetch_rows(fcm_sampler *s, uint32_t chain, std::vector<uint32_t> &rows)
+{
+    if (chain >= s->params.nchains) return fail(FCM_ERR_INVALID, "chain %u out of range", chain);
+    int rc = fcm_sampler_sync(s);
+    if (rc) return rc;
+    rows.resize((size_t)s->params.rows_per_chain);
+    HIP_TRY(hipMemcpy(rows.data(), s->d_rows.as<uint32_t>() + (size_t)chain * s->params.rows_per_chain,
+                      rows.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_get_edges(fcm_sampler *s, uint32_t chain, fcm_node *out, uint64_t cap, uint64_t *m)
+{
+    if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
+    std::vector<uint32_t> rows;
+    int rc = fetch_rows(s, chain, rows);
+    if (rc) return rc;
+    const uint32_t nw = (s->n + 31) / 32;
+    uint64_t i = 0;
+    for (uint32_t a = 0; a < s->n; ++a)
+        for (uint32_t w = 0; w < nw; ++w) {
+            uint32_t x = rows[(size_t)a * s->stride32 + w];
+            while (x) {
+                const uint32_t b = w * 32 + (uint32_t)__builtin_ctz(x);
+                x &= x - 1;
+                if (out && i < cap) { out[2 * i] = a; out[2 * i + 1] = b; }
+                ++i;
+            }
+        }
+    if (m) *m = i;
+    return FCM_OK;
+}
+
+// BitOutput::save record, src/io.rs:152-159 (slot order) and :180-194 (packing)
+extern "C" int fcm_sampler_get_edgebits(fcm_sampler *s, uint32_t chain, uint8_t *out, uint64_t cap, uint64_t *nbytes)
+{
+    if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
+    const uint64_t U = s->ue.size() / 2;
+    const uint64_t need = (2 * U + 7) / 8;
+    if (nbytes) *nbytes = need;
+    if (!out) return FCM_OK;
+    if (cap < need) return fail(FCM_ERR_INVALID, "edgebits buffer too small: need %llu", (unsigned long long)need);
+    std::vector<uint32_t> rows;
+    int rc = fetch_rows(s, chain, rows);
+    if (rc) return rc;
+    memset(out, 0, (size_t)need);
+    auto has = [&](uint32_t a, uint32_t b) { return (rows[(size_t)a * s->stride32 + (b >> 5)] >> (b & 31)) & 1u; };
+    for (uint64_t e = 0; e < U; ++e) {
+        const uint32_t a = s->ue[2 * e], b = s->ue[2 * e + 1];
+        if (has(a, b)) out[(2 * e) >> 3] |= (uint8_t)(1u << ((2 * e) & 7));          // slot [big,small]: a<b false sorts first
+        if (has(b, a)) out[(2 * e + 1) >> 3] |= (uint8_t)(1u << ((2 * e + 1) & 7));  // slot [small,big]
+    }
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_get_double_slots(fcm_sampler *s, uint32_t chain, uint32_t *out, uint64_t cap, uint64_t *n)
+{
+    if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
+    if (chain >= s->params.nchains) return fail(FCM_ERR_INVALID, "chain %u out of range", chain);
+    int rc = fcm_sampler_sync(s);
+    if (rc) return rc;
+    const uint64_t D = s->params.D;
+    if (n) *n = D;
+    if (out && D) {
+        const uint64_t k = std::min<uint64_t>(D, cap);
+        HIP_TRY(hipMemcpy(out, s->d_dbl.as<uint32_t>() + (size_t)chain * s->params.dbl_stride, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out)
+{
+    if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    *out = s->info;
+    return FCM_OK;
+}

@@ -1,0 +1,219 @@
+/*
+ * fcm.h — C ABI of libfcm.so, the MI355X-native drop-in for the hot path of
+ * TheJonny/flag-complex-mcmc: the `sample` binary's edge-flip MCMC loop
+ * (reference src/lib.rs:181-194 in `--simple` mode) and the directed-flag-
+ * complex simplex counter it calls (`flagser_count`, reference
+ * src/lib.rs:51,63,71,130; legacy FFI src/flagser.rs:7-10).
+ *
+ * Plain C types only.  All functions return an int status (0 = FCM_OK) unless
+ * stated otherwise; fcm_last_error() returns a thread-local message for the
+ * last failing call.  Nothing throws across this boundary.
+ *
+ * Every compute entry point runs on an AMD GPU through HIP.  There is no CPU
+ * fallback: without a usable device the call fails with FCM_ERR_NO_DEVICE.
+ *
+ * Threading: handles are not thread-safe; distinct handles may be used from
+ * distinct threads (the reference runs independent `State`s on OS threads,
+ * src/bin/all_cxs.rs:33-38).
+ */
+#ifndef FCM_H
+#define FCM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCM_OK 0
+#define FCM_ERR_INVALID 1      /* bad argument */
+#define FCM_ERR_NO_DEVICE 2    /* no HIP device / device index out of range */
+#define FCM_ERR_HIP 3          /* a HIP runtime call failed */
+#define FCM_ERR_UNSUPPORTED 4  /* valid input outside what this build supports */
+#define FCM_ERR_IO 5           /* file could not be read / written / parsed */
+#define FCM_ERR_PANIC 6        /* the reference would panic on this input */
+#define FCM_ERR_NOMEM 7
+#define FCM_ERR_INTERNAL 8     /* device-side consistency check failed */
+
+/* Count vectors handled by the device kernels hold at most this many entries
+ * (dimensions 0..15).  The reference has no cap; inputs whose
+ * undirected clique number exceeds 16 are refused unless a dim_cap is given. */
+#define FCM_MAX_COUNTS 16
+
+/* Largest |N(a) cap N(b)| + 2 the step kernel supports (one 64-lane wave holds
+ * one local vertex per lane). */
+#define FCM_MAX_LOCAL 64
+
+typedef uint32_t fcm_node;     /* reference `Node` = u32 (src/flagser.rs:5,9) */
+
+const char *fcm_last_error(void);
+const char *fcm_version(void);
+
+/* Number of visible HIP devices (0 when none). */
+int fcm_device_count(int *count);
+
+/* ------------------------------------------------------------------------ */
+/* Legacy entry point.  Replaces, symbol for symbol, the C function the      */
+/* reference binds at src/flagser.rs:7-10:                                   */
+/*   fn flagser_count_unweighted(nvertices: size_t, nedges: size_t,          */
+/*        edges: *const [Node; 2], res_size: *mut size_t) -> *mut size_t;    */
+/* Ownership as at src/flagser.rs:14-19: the result is malloc'd here, its    */
+/* length is written to *res_size, the caller copies and free()s it.  The    */
+/* edge buffer is borrowed for the call.  On failure returns NULL with       */
+/* *res_size = 0.  Runs on HIP device 0 (env FCM_DEVICE overrides).          */
+/* ------------------------------------------------------------------------ */
+size_t *flagser_count_unweighted(size_t nvertices, size_t nedges,
+                                 const fcm_node (*edges)[2], size_t *res_size);
+
+/* ------------------------------------------------------------------------ */
+/* Graph: the `flag_complex::Graph` surface the reference uses               */
+/* (call sites src/lib.rs:69,83,125-128,294,310,333,341; */
+/* src/io.rs:26,31,39,41).  Host-side handle; adjacency kept as out-row      */
+/* bitmaps, the layout the device kernels consume.                           */
+/* ------------------------------------------------------------------------ */
+typedef struct fcm_graph fcm_graph;
+
+int fcm_graph_new_disconnected(uint32_t nnodes, fcm_graph **out);
+int fcm_graph_from_edges(uint32_t nnodes, uint64_t nedges, const fcm_node *edges /* [nedges][2] */,
+                         fcm_graph **out);
+int fcm_graph_clone(const fcm_graph *g, fcm_graph **out);
+void fcm_graph_destroy(fcm_graph *g);
+
+uint32_t fcm_graph_nnodes(const fcm_graph *g);
+uint64_t fcm_graph_nedges(const fcm_graph *g);
+int fcm_graph_has_edge(const fcm_graph *g, fcm_node a, fcm_node b);        /* 1/0; 0 if out of range */
+int fcm_graph_set_edge(fcm_graph *g, fcm_node a, fcm_node b, int present);
+int fcm_graph_add_edge(fcm_graph *g, fcm_node a, fcm_node b);
+int fcm_graph_remove_edge(fcm_graph *g, fcm_node a, fcm_node b);
+/* edges(): ascending (from,to).  Writes min(cap,m) pairs, *m = total. */
+int fcm_graph_edges(const fcm_graph *g, fcm_node *out, uint64_t cap, uint64_t *m);
+/* undirected_edges(): one [a,b] per adjacent pair, a > b, ascending (a,b). */
+int fcm_graph_undirected_edges(const fcm_graph *g, fcm_node *out, uint64_t cap, uint64_t *m);
+
+/* flagser_count() / flag_complex::count_cells (src/lib.rs:51,130): counts[d]
+ * = number of directed d-simplices; *len = 1 + highest dimension present.
+ * Runs the HIP counting kernel on `device`. */
+int fcm_graph_flagser_count(const fcm_graph *g, int device, uint64_t *counts, int cap, int *len);
+
+/* io::read_flag_file (src/io.rs:18-35) and io::save_flag_file (:37-48). */
+int fcm_read_flag_file(const char *path, fcm_graph **out);
+int fcm_save_flag_file(const char *path, const fcm_graph *g);
+
+/* ------------------------------------------------------------------------ */
+/* Bounds (src/lib.rs:113-161) and the init maths of                         */
+/* initialize_new_sampler (src/bin/sample.rs:87-102).                        */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t flag_count_min[FCM_MAX_COUNTS + 1];
+    int32_t min_len;
+    uint64_t flag_count_max[FCM_MAX_COUNTS + 1];
+    int32_t max_len;
+} fcm_bounds;
+
+/* Target bounds: exact for d<2, floor(s*(1-r)) / floor(s*(1+r)) in f64 for
+ * d>=2 (src/bin/sample.rs:89-95). */
+int fcm_target_bounds(const uint64_t *flag_count, int len, double target_relaxation, fcm_bounds *out);
+
+/* Bounds::calculate (src/lib.rs:119-156), including the SEO shortcut and the
+ * reference's (x-1)! `factorial` (src/util.rs:65-71).  `flag_count` is the
+ * initial state's count vector.  The undirected clique counts are computed
+ * with the HIP counting kernel on `device` and optionally returned.  Inputs on
+ * which the reference panics give FCM_ERR_PANIC. */
+int fcm_bounds_calculate(const fcm_graph *initial_graph, const uint64_t *flag_count, int len,
+                         const fcm_bounds *target_bounds, int device, fcm_bounds *out,
+                         uint64_t *ncliques /* optional, FCM_MAX_COUNTS+1 */, int *ncliques_len);
+
+/* Bounds::check (src/lib.rs:157-160) via all_le (src/util.rs:53-63). */
+int fcm_bounds_check(const fcm_bounds *b, const uint64_t *flag_count, int len);
+
+/* ceil(2 * E * log2(E)) (src/bin/sample.rs:102). */
+uint64_t fcm_default_sample_distance(uint64_t nedges);
+
+/* ------------------------------------------------------------------------ */
+/* Sampler: a batch of independent MCMCSampler chains (src/lib.rs:163-198)   */
+/* bound to one device.  One persistent 64-lane workgroup per chain.         */
+/* ------------------------------------------------------------------------ */
+typedef struct fcm_sampler fcm_sampler;
+
+typedef struct {
+    uint32_t n_chains;        /* chains held by this handle */
+    uint32_t first_chain_id;  /* global id of chain 0: RNG stream = (seed, first_chain_id + i) */
+    uint64_t seed;            /* `--seed` (src/bin/sample.rs:43-45) */
+    double move_weights[4];   /* [flip, double-move, clique_permute, clique_swap] (sample.rs:16-17);
+                                 entries 2,3 must be 0 in this build */
+    uint64_t sample_distance; /* proposals per next(); 0 = default (sample.rs:102) */
+    int32_t dim_cap;          /* 0 = lossless (track every reachable dimension); d>0 = track
+                                 dimensions 0..d only ("truncated") */
+    int32_t device;           /* HIP device index */
+} fcm_sampler_config;
+
+/* State::new + MCMCSampler construction (src/lib.rs:38-58; sample.rs:104):
+ * builds the static neighbourhood table (src/lib.rs:331-356), counts the
+ * initial graph on the device, replicates the orientation bitmap per chain. */
+int fcm_sampler_create(const fcm_graph *graph, const fcm_bounds *bounds,
+                       const fcm_sampler_config *cfg, fcm_sampler **out);
+void fcm_sampler_destroy(fcm_sampler *s);
+
+/* Launch stream (a hipStream_t passed as void*); NULL = the handle's own. */
+int fcm_sampler_set_stream(fcm_sampler *s, void *hip_stream);
+
+/* `n_proposals` iterations of the loop at src/lib.rs:182-192 on every chain.
+ * Asynchronous: returns after the launch; fcm_sampler_sync waits and reports
+ * device-side failures. */
+int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals);
+/* MCMCSampler::next (src/lib.rs:181-194): sample_distance proposals, then sync. */
+int fcm_sampler_next(fcm_sampler *s);
+int fcm_sampler_sync(fcm_sampler *s);
+/* Duration of the most recent step kernel, from HIP events recorded on the
+ * launch stream around it.  Syncs. */
+int fcm_sampler_last_step_ms(fcm_sampler *s, float *ms);
+
+/* Number of count entries tracked per chain (<= FCM_MAX_COUNTS). */
+int fcm_sampler_ncounts(const fcm_sampler *s);
+uint64_t fcm_sampler_sample_distance(const fcm_sampler *s);
+/* Sync, then copy per-chain flag_count vectors: out[n_chains][ncounts];
+ * count_len[i] (optional) = the reference's flag_count.len() for chain i
+ * (never shrinks, src/lib.rs:72-74,89-91). */
+int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
+
+/* Per-chain counters, out[n_chains][FCM_NSTATS]. */
+#define FCM_NSTATS 8
+#define FCM_STAT_SAMPLED 0    /* MCMCSampler::sampled (src/lib.rs:176) */
+#define FCM_STAT_ACCEPTED 1   /* MCMCSampler::accepted (src/lib.rs:177) */
+#define FCM_STAT_EMPTY 2      /* proposals whose transition was empty */
+#define FCM_STAT_FLIP 3       /* non-empty single_edge_flip proposals */
+#define FCM_STAT_DMOVE 4      /* non-empty double_edge_move proposals */
+#define FCM_STAT_SUM_K 5      /* sum over evaluated edges of |N(a) cap N(b)| */
+#define FCM_STAT_COUNT_LEN 6
+#define FCM_STAT_STATUS 7     /* 0 ok; non-zero = device-side check failed */
+int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out);
+
+/* Directed edge list of one chain's current graph, ascending (from,to). */
+int fcm_sampler_get_edges(fcm_sampler *s, uint32_t chain, fcm_node *out, uint64_t cap, uint64_t *m);
+/* One `BitOutput::save` record (src/io.rs:169-205): slots = both directions
+ * of every adjacent pair sorted by (max,min,a<b), packed LSB-first, padded to
+ * a byte.  *nbytes = ceil(2*U/8). */
+int fcm_sampler_get_edgebits(fcm_sampler *s, uint32_t chain, uint8_t *out, uint64_t cap, uint64_t *nbytes);
+/* The chain's reciprocal-pair slot list (DESIGN.md draw spec), for parity tests. */
+int fcm_sampler_get_double_slots(fcm_sampler *s, uint32_t chain, uint32_t *out, uint64_t cap, uint64_t *n);
+
+/* Static facts about the sampler (for bench accounting). */
+typedef struct {
+    uint32_t n;                /* vertices */
+    uint32_t row_words;        /* 64-bit words per bitmap row actually stored (padded) */
+    uint64_t n_undirected;     /* U */
+    uint64_t n_double;         /* D (constant under the simple moves) */
+    uint32_t k_max;            /* max |N(a) cap N(b)| */
+    double k_mean;
+    uint64_t bytes_per_chain;  /* HBM bytes of mutable state per chain */
+    uint64_t bytes_static;     /* HBM bytes of shared read-only tables */
+    int32_t ncounts;
+    int32_t lossless;          /* 1 if every reachable dimension is tracked */
+} fcm_sampler_info;
+int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCM_H */

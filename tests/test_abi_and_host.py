@@ -1,0 +1,138 @@
+"""CPU: the C-ABI library loads, exports every symbol include/fcm.h declares,
+fails loudly without a GPU, and its host-side logic (Graph surface, .flag I/O,
+Bounds arithmetic) agrees with the oracle.  No kernel runs here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import known_answers, load_flag_fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fcm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(fcm_[a-z0-9_]+|flagser_count_unweighted)\s*\(", text))
+    return sorted(names - {"fcm_node"})  # `const fcm_node (*edges)[2]` is a type, not a function
+
+
+def test_header_symbols_are_exported(fcm):
+    import ctypes
+    L = ctypes.CDLL(fcm.LIB_PATH)
+    names = _declared_symbols()
+    assert "flagser_count_unweighted" in names and len(names) > 30
+    for n in names:
+        assert hasattr(L, n), "include/fcm.h declares %s but libfcm.so does not export it" % n
+
+
+def test_python_binding_covers_every_declared_symbol(fcm):
+    from flag_complex_mcmc_amd import _ffi
+    assert sorted(_ffi.SIGNATURES) == _declared_symbols()
+
+
+def test_no_gpu_fails_loudly(fcm):
+    if fcm.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    g = fcm.Graph.from_edges(3, [(0, 1), (1, 2)])
+    with pytest.raises(fcm.FcmError) as ei:
+        g.flagser_count()
+    assert ei.value.code == 2 and "no CPU path" in str(ei.value)
+    with pytest.raises(fcm.FcmError):
+        fcm.MCMCSampler(g, fcm.Bounds([3, 2], [3, 2]), n_chains=1)
+    with pytest.raises(fcm.FcmError):
+        fcm.count_unweighted(3, [(0, 1)])
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "flag_complex_mcmc_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle_ffi" not in txt and "fcm_oracle" not in txt and "libfcm_oracle" not in txt, os.path.join(dp, f)
+
+
+def test_graph_surface(fcm, oracle):
+    n, e = load_flag_fixture("bug_calc_relax_de.flag")
+    g = fcm.Graph.from_edges(n, e)
+    o = oracle.Graph.from_edges(n, e)
+    assert g.nnodes() == n and g.nedges() == len(o.edges())
+    assert (g.edges() == o.edges()).all()
+    assert (g.undirected_edges() == o.undirected_edges()).all()
+    a, b = map(int, e[0])
+    assert g.has_edge(a, b) and not g.has_edge(n + 5, 0)
+    g.remove_edge(a, b)
+    assert not g.has_edge(a, b) and g.nedges() == len(e) - 1
+    g.set_edge(a, b, True)
+    g.add_edge(a, b)  # idempotent
+    assert g.nedges() == len(e)
+    with pytest.raises(fcm.FcmError):
+        g.add_edge(0, n)
+    h = g.clone()
+    h.remove_edge(a, b)
+    assert g.has_edge(a, b)
+    g2 = fcm.Graph.new_disconnected(5)
+    assert g2.nnodes() == 5 and g2.nedges() == 0 and len(g2.undirected_edges()) == 0
+
+
+def test_flag_file_io(fcm, golden_dir, tmp_path):
+    for f in sorted(os.listdir(golden_dir)):
+        if not f.endswith(".flag"):
+            continue
+        n, e = load_flag_fixture(f)
+        g = fcm.read_flag_file(os.path.join(golden_dir, f))
+        assert g.nnodes() == n
+        assert sorted(map(tuple, g.edges().tolist())) == sorted(set(map(tuple, e.tolist())))
+        out = tmp_path / f
+        fcm.save_flag_file(str(out), g)
+        lines = out.read_text().split("\n")
+        assert lines[0] == "dim 0:" and lines[2] == "dim 1:"                 # src/io.rs:38-40
+        assert lines[1] == " ".join(["1"] * n)
+        assert lines[3] == "%d %d 1" % tuple(g.edges()[0])                   # sorted, weight column (io.rs:41-45)
+        g2 = fcm.read_flag_file(str(out))
+        assert (g2.edges() == g.edges()).all()
+
+
+def test_flag_file_edge_cases(fcm, tmp_path):
+    p = tmp_path / "a.flag"
+    p.write_text("dim 0:\n1  1 1 \ndim 1:\n0 1\n\n 1   2 0.5 extra\r\n2\n")
+    g = fcm.read_flag_file(str(p))
+    assert g.nnodes() == 3 and g.edges().tolist() == [[0, 1], [1, 2]]       # blank / one-token lines skipped (io.rs:30)
+    p.write_text("dim 0:\n1 1\ndim 1:\n0 x\n")
+    with pytest.raises(fcm.FcmError):                                       # reference: parse().unwrap() panics
+        fcm.read_flag_file(str(p))
+    with pytest.raises(fcm.FcmError):
+        fcm.read_flag_file(str(tmp_path / "missing.flag"))
+    p.write_text("dim 0:\n\ndim 1:\n")
+    assert fcm.read_flag_file(str(p)).nnodes() == 0                         # empty graph
+
+
+def test_target_bounds_and_check_match_oracle(fcm, oracle):
+    fc = [1000, 100151, 1005709, 1013125, 102824, 1084]
+    for r in (0.01, 0.05, 0.0):
+        b = fcm.Bounds.target(fc, r)
+        mn, mx = oracle.target_bounds(fc, r).lists()
+        assert b.flag_count_min == mn and b.flag_count_max == mx
+    b = fcm.Bounds([1, 2, 3], [1, 2, 5, 10])
+    assert b.check([1, 2, 4]) and b.check([1, 2, 5, 10]) and not b.check([1, 2, 6])
+    assert not b.check([1, 2, 4, 0, 1])      # longer than max: padded with 0 (src/util.rs:53-57)
+    assert not b.check([1, 2])               # shorter than min: 0 < 3
+    assert fcm.default_sample_distance(100151) == oracle.default_sample_distance(100151)
+
+
+def test_graph_generators_are_deterministic(fcm):
+    from flag_complex_mcmc_amd import graphs
+    e1 = graphs.random_with_p(200, 0.1, seed=0)
+    e2 = graphs.random_with_p(200, 0.1, seed=0)
+    assert (e1 == e2).all() and (e1[:, 0] != e1[:, 1]).all()
+    assert abs(len(e1) - 0.1 * 200 * 200) < 600
+    e3 = graphs.random_edge_draws(1000, 5000, seed=1)
+    assert len(np.unique(e3[:, 0].astype(np.int64) * 1000 + e3[:, 1])) == len(e3) and (e3[:, 0] != e3[:, 1]).all()
+    ka = known_answers()
+    assert graphs.simplex(3).tolist() == ka["ex00"]["edges"]
+    assert graphs.clique(3).tolist() == ka["ex03"]["edges"]
+    s = graphs.seoify(graphs.clique(4), seed=0)
+    assert len(s) == 10

@@ -1,0 +1,297 @@
+"""GPU: the HIP path (through the C ABI) against the oracle, bit for bit.
+
+Tolerance is 0 everywhere: the accept rule is integer-only, so a
+GPU chain and its oracle twin on the same Philox stream must agree on
+sampled/accepted, every count, every edge and the reciprocal-pair slot list.
+"""
+import numpy as np
+import pytest
+
+from helpers import compare_chain, known_answers, load_flag_fixture, setup_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _case_graph(name, rec):
+    if name.endswith(".flag"):
+        return load_flag_fixture(name)
+    return rec["n"], np.array(rec["edges"], np.uint32)
+
+
+def test_extension_is_loaded_and_sees_the_gpu(fcm):
+    assert fcm.device_count() >= 1
+    import ctypes
+    assert ctypes.CDLL(fcm.LIB_PATH).fcm_version
+
+
+# ---------------------------------------------------------------- counter ----
+def test_flagser_count_known_answers(fcm):
+    for name, rec in known_answers().items():
+        n, e = _case_graph(name, rec)
+        g = fcm.Graph.from_edges(n, e)
+        assert g.flagser_count() == rec["flag_count"], name
+        # the legacy symbol the reference binds (src/flagser.rs:7-21)
+        assert fcm.count_unweighted(n, e) == rec["flag_count"], name
+
+
+def test_flagser_count_edge_cases(fcm):
+    assert fcm.Graph.new_disconnected(0).flagser_count() == []
+    assert fcm.Graph.new_disconnected(5).flagser_count() == [5]
+    assert fcm.count_unweighted(2, [(0, 1), (0, 1), (1, 1)]) == [2, 1]   # duplicates and loops ignored
+    assert fcm.count_unweighted(2, [(0, 1), (1, 0)]) == [2, 2]           # reciprocal pair counts twice
+    with pytest.raises(fcm.FcmError):
+        fcm.count_unweighted(2, [(0, 2)])
+
+
+def test_flagser_count_vs_oracle_random(fcm, oracle):
+    from flag_complex_mcmc_amd import graphs
+    for n, p, seed in [(50, 0.3, 0), (130, 0.15, 1), (300, 0.1, 2), (64, 0.5, 3), (1000, 0.02, 4)]:
+        e = graphs.random_with_p(n, p, seed)
+        assert fcm.Graph.from_edges(n, e).flagser_count() == oracle.Graph.from_edges(n, e).flagser_count(), (n, p)
+
+
+def test_flagser_count_high_dimension(fcm, oracle):
+    from flag_complex_mcmc_amd import graphs
+    # a transitive tournament on 14 vertices: one 13-simplex, C(14,d+1) d-simplices
+    e = graphs.simplex(13)
+    import math
+    want = [math.comb(14, d + 1) for d in range(14)]
+    assert fcm.Graph.from_edges(14, e).flagser_count() == want
+    assert oracle.Graph.from_edges(14, e).flagser_count() == want
+    # 17 vertices would need dimension 16 > 15: refused, not truncated
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.Graph.from_edges(17, graphs.simplex(16)).flagser_count()
+    assert ei.value.code == 4
+
+
+def test_count_config3_known_answer(fcm):
+    """ER n=1000 p=0.10 seed 0 (BASELINE config 3): committed golden counts,
+    produced by the oracle (golden/make_er_counts.py)."""
+    import json, os
+    from flag_complex_mcmc_amd import graphs
+    from helpers import GOLDEN
+    rec = json.load(open(os.path.join(GOLDEN, "er_counts.json")))["n1000_p0.10_seed0"]
+    e = graphs.random_with_p(1000, 0.10, 0)
+    assert len(e) == rec["m"]
+    g = fcm.Graph.from_edges(1000, e)
+    assert g.flagser_count() == rec["flag_count"]
+
+
+# ----------------------------------------------------------------- bounds ----
+def test_bounds_calculate_vs_oracle(fcm, oracle):
+    from flag_complex_mcmc_amd import graphs
+    cases = [load_flag_fixture(f) for f in ("counterexample_any_order.flag", "bug_calc_relax_de.flag")]
+    cases += [(60, graphs.random_with_p(60, 0.3, 3)), (200, graphs.random_with_p(200, 0.1, 5))]
+    for n, e in cases:
+        go = oracle.Graph.from_edges(n, e)
+        st = oracle.State(go)
+        fc = st.flag_count
+        bo, ncl_o = oracle.bounds_calculate(st, oracle.target_bounds(fc, 0.01))
+        gg = fcm.Graph.from_edges(n, e)
+        bg, ncl_g = fcm.Bounds.calculate(gg, fc, fcm.Bounds.target(fc, 0.01), return_ncliques=True)
+        assert (bg.flag_count_min, bg.flag_count_max) == bo.lists()
+        assert ncl_g == ncl_o
+
+
+def test_bounds_calculate_panics_like_the_reference(fcm):
+    # reciprocal pair but no 2-simplex: flag_count_max[2] is out of range (src/lib.rs:151)
+    g = fcm.Graph.from_edges(3, [(0, 1), (1, 0), (1, 2)])
+    fc = g.flagser_count()
+    assert fc == [3, 3]
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.01))
+    assert ei.value.code == 6
+
+
+# ------------------------------------------------------------ trajectories ----
+def _run_parity(fcm, oracle, n, e, n_chains, steps, seed, weights=(0.5, 0.5, 0.0, 0.0), relaxation=0.01,
+                first_chain_id=0, check_chains=None, bounds=None):
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e, relaxation)
+    if bounds is not None:
+        b_g = fcm.Bounds(*bounds)
+        b_o = oracle.Bounds.from_lists(*bounds)
+    s = fcm.MCMCSampler(gg, b_g, n_chains=n_chains, seed=seed, move_weights=weights, first_chain_id=first_chain_id)
+    check_chains = list(range(n_chains)) if check_chains is None else check_chains
+    twins = {c: oracle.Chain(go, b_o, weights=weights, seed=seed, chain_id=first_chain_id + c) for c in check_chains}
+    for nstep in steps:
+        s.step(nstep)
+        for c, tw in twins.items():
+            tw.step(nstep)
+            compare_chain(s, c, tw, ctx=(n, c, nstep))
+    return s, twins
+
+
+def test_trajectory_fixtures(fcm, oracle):
+    for f in ("counterexample_any_order.flag", "counterexample_seo_greedy_5_start.flag", "bug_calc_relax_de.flag"):
+        n, e = load_flag_fixture(f)
+        s, tw = _run_parity(fcm, oracle, n, e, n_chains=3, steps=[1, 63, 64, 65, 500], seed=5)
+        st = s.stats()
+        assert (st["sampled"] == 693).all()
+        # no reciprocal pairs: every double-move proposal is empty and accepted (src/lib.rs:324,185-187)
+        assert (st["n_dmove"] == 0).all() and (st["n_empty"] > 250).all()
+
+
+def test_trajectory_er_with_reciprocal_pairs(fcm, oracle):
+    from flag_complex_mcmc_amd import graphs
+    e = graphs.random_with_p(150, 0.15, seed=2)
+    s, tw = _run_parity(fcm, oracle, 150, e, n_chains=4, steps=[100, 900, 1000], seed=9, first_chain_id=17)
+    st = s.stats()
+    assert (st["n_dmove"] > 0).all() and (st["n_flip"] > 0).all()
+    # different chains took different paths
+    assert len({tuple(s.flag_count(c)) for c in range(4)}) > 1
+
+
+def test_trajectory_rejections_happen_and_match(fcm, oracle):
+    """Tight bounds force rejections, exercising the drop path (src/lib.rs:189-191)."""
+    from flag_complex_mcmc_amd import graphs
+    e = graphs.random_with_p(120, 0.2, seed=4)
+    go = oracle.Graph.from_edges(120, e)
+    fc = go.flagser_count()
+    mn = list(fc); mx = list(fc)
+    for d in range(2, len(fc)):
+        mn[d] = fc[d] - 3
+        mx[d] = fc[d] + 3
+    s, tw = _run_parity(fcm, oracle, 120, e, n_chains=2, steps=[300, 700], seed=1, bounds=(mn, mx))
+    st = s.stats()
+    assert (st["accepted"] < st["sampled"]).all()
+    assert (st["accepted"] > st["n_empty"]).all()
+
+
+def test_trajectory_only_flips_and_only_double_moves(fcm, oracle):
+    from flag_complex_mcmc_amd import graphs
+    e = graphs.random_with_p(100, 0.2, seed=6)
+    _run_parity(fcm, oracle, 100, e, n_chains=2, steps=[400], seed=3, weights=(1.0, 0.0, 0.0, 0.0))
+    _run_parity(fcm, oracle, 100, e, n_chains=2, steps=[400], seed=3, weights=(0.0, 1.0, 0.0, 0.0))
+    _run_parity(fcm, oracle, 100, e, n_chains=2, steps=[400], seed=3, weights=(0.2, 0.8, 0.0, 0.0))
+
+
+def test_new_top_dimension_and_count_len(fcm, oracle):
+    """ex02-like growth: a flip can create a simplex of a dimension not present
+    before; flag_count grows and never shrinks (src/lib.rs:72-74)."""
+    # 0->1,0->2,1->2 plus 3 joined so that flipping creates / destroys 3-simplices
+    e = np.array([(0, 1), (0, 2), (1, 2), (0, 3), (1, 3), (3, 2)], np.uint32)
+    go = oracle.Graph.from_edges(4, e)
+    fc = go.flagser_count()
+    # generous hand-made bounds so every move is accepted
+    mn = [4, 6, 0, 0]
+    mx = [4, 6, 100, 100, 100]
+    _run_parity(fcm, oracle, 4, e, n_chains=8, steps=[1, 1, 1, 5, 50], seed=2, weights=(1.0, 0.0, 0.0, 0.0), bounds=(mn, mx))
+
+
+def test_chain_identity_is_independent_of_batching(fcm, oracle):
+    """Chain c's stream is (seed, first_chain_id + c): splitting chains over
+    handles (= over GPUs) must not change any trajectory."""
+    from flag_complex_mcmc_amd import graphs
+    e = graphs.random_with_p(100, 0.15, seed=8)
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, 100, e)
+    whole = fcm.MCMCSampler(gg, b_g, n_chains=6, seed=4)
+    lo = fcm.MCMCSampler(gg, b_g, n_chains=3, seed=4, first_chain_id=0)
+    hi = fcm.MCMCSampler(gg, b_g, n_chains=3, seed=4, first_chain_id=3)
+    for s in (whole, lo, hi):
+        s.step(777)
+    w = whole.flag_counts()
+    assert (w[:3] == lo.flag_counts()).all() and (w[3:] == hi.flag_counts()).all()
+    for c in range(3):
+        assert (whole.edges(c) == lo.edges(c)).all() and (whole.edges(3 + c) == hi.edges(c)).all()
+    # one launch of 777 == 777 launches of 1 (state is carried in HBM between launches)
+    one = fcm.MCMCSampler(gg, b_g, n_chains=2, seed=4)
+    for _ in range(130):
+        one.step(1)
+    ref = fcm.MCMCSampler(gg, b_g, n_chains=2, seed=4)
+    ref.step(130)
+    assert (one.flag_counts() == ref.flag_counts()).all() and (one.edges(1) == ref.edges(1)).all()
+
+
+def test_next_uses_sample_distance(fcm, oracle):
+    n, e = load_flag_fixture("counterexample_any_order.flag")
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, b_g, n_chains=2, seed=0)
+    assert s.sample_distance == oracle.default_sample_distance(18)          # src/bin/sample.rs:102
+    s.next()
+    assert (s.sampled == s.sample_distance).all()
+    tw = oracle.Chain(go, b_o, seed=0, chain_id=1, sample_distance=s.sample_distance)
+    tw.next()
+    compare_chain(s, 1, tw)
+    assert abs(s.acceptance_ratio()[1] - tw.acceptance_ratio()) == 0.0
+
+
+def test_initialize_new_sampler_end_to_end(fcm, oracle, golden_dir):
+    import os
+    path = os.path.join(golden_dir, "bug_calc_relax_de.flag")
+    s = fcm.initialize_new_sampler(path, target_relaxation=0.01, seed=3, n_chains=2, simple=True, sample_distance=200)
+    go = oracle.Graph.read_flag_file(path)
+    st = oracle.State(go)
+    bo, _ = oracle.bounds_calculate(st, oracle.target_bounds(st.flag_count, 0.01))
+    assert (s.bounds.flag_count_min, s.bounds.flag_count_max) == bo.lists()
+    s.next()
+    tw = oracle.Chain(go, bo, seed=3, chain_id=0, sample_distance=200)
+    tw.next()
+    compare_chain(s, 0, tw)
+
+
+def test_unsupported_inputs_fail_loudly(fcm):
+    from flag_complex_mcmc_amd import graphs
+    g = fcm.Graph.from_edges(4, graphs.simplex(3))
+    b = fcm.Bounds([4, 6, 0, 0], [4, 6, 9, 9])
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MCMCSampler(g, b, move_weights=fcm.MOVE_DISTRIBUTION)     # clique moves: SURVEY.md 8f
+    assert ei.value.code == 4
+    with pytest.raises(fcm.FcmError):
+        fcm.MCMCSampler(g, b, move_weights=(0, 0, 0, 0))
+    # a dense graph whose common neighbourhoods exceed one wave
+    big = fcm.Graph.from_edges(80, graphs.simplex(79))
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MCMCSampler(big, fcm.Bounds([80], [80]))
+    assert ei.value.code == 4
+
+
+# -------------------------------------------------- edgebits (src/io.rs) -----
+def test_edgebits_layout(fcm, tmp_path):
+    from flag_complex_mcmc_amd import graphs
+    e = graphs.random_with_p(40, 0.3, seed=1)
+    g = fcm.Graph.from_edges(40, e)
+    fc = g.flagser_count()
+    b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.05))
+    s = fcm.MCMCSampler(g, b, n_chains=2, seed=1)
+    s.step(300)
+    for c in range(2):
+        cur = s.graph(c)
+        # slot list per src/io.rs:152-159: every edge and its reverse, sorted by (max,min,a<b), dedup
+        slots = sorted({(int(a), int(b)) for a, b in e} | {(int(b), int(a)) for a, b in e},
+                       key=lambda ab: (max(ab), min(ab), ab[0] < ab[1]))
+        bits = [1 if cur.has_edge(a, bb) else 0 for a, bb in slots]
+        want = np.packbits(np.array(bits, np.uint8), bitorder="little")
+        assert (s.edgebits(c) == want).all()
+    out = fcm.BitOutput(g, str(tmp_path / "lab-001"))
+    out.save(s, 0)
+    out.save(s, 1)
+    out.flush()
+    data = (tmp_path / "lab-001" / "0.edgebits").read_bytes()
+    assert len(data) == 2 * len(s.edgebits(0)) and (tmp_path / "lab-001" / "graph.flag").exists()
+
+
+# ----------------------------------------- full-size, size-independent checks -
+def test_full_size_config3_invariants(fcm):
+    """BASELINE config 3 shape (ER n=1000 p=0.10), many chains, long enough that
+    the oracle is not run: check properties that hold at any size.
+      * incrementally maintained counts == from-scratch recount of the final graph
+      * count[0], count[1] and pr(G) unchanged (reference README.md:3)
+      * final counts within the bounds
+      * sampled == requested; accepted <= sampled; empty+flip+dmove == sampled."""
+    from flag_complex_mcmc_amd import graphs
+    n = 1000
+    e = graphs.random_with_p(n, 0.10, 0)
+    s = fcm.initialize_new_sampler(fcm.Graph.from_edges(n, e), n_chains=256, seed=0)
+    s.step(2000)
+    st = s.stats()
+    assert (st["sampled"] == 2000).all() and (st["accepted"] <= st["sampled"]).all()
+    assert (st["n_empty"] + st["n_flip"] + st["n_dmove"] == 2000).all()
+    counts = s.flag_counts()
+    und0 = fcm.Graph.from_edges(n, e).undirected_edges()
+    for c in (0, 100, 255):
+        g = s.graph(c)
+        assert g.flagser_count() == s.flag_count(c)
+        assert (g.undirected_edges() == und0).all() and g.nedges() == len(e)
+        assert s.bounds.check(s.flag_count(c))
+    assert (counts[:, 0] == n).all() and (counts[:, 1] == len(e)).all()
+    assert len({tuple(r) for r in counts.tolist()}) > 200   # chains diverged
