@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: edge-flip proposals/sec on the BASELINE
+config-3 workload (Erdos-Renyi digraph n=1000, p=0.10, 4096 independent chains
+per GPU, `--simple` move mix, target_relaxation 0.01).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one launch of the persistent step kernel: every chain runs
+--proposals iterations of the reference loop src/lib.rs:182-192.  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "edge-flip proposals/sec/GPU (n=1k graph); bit-exact simplex counts"  # BASELINE.json
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(d, n):
+    """W = 8*ceil(n/64) bytes per row; non-empty flip reads
+    (k+4) rows + 64 B of word updates, double-edge move (k1+k2+8) rows + 128 B,
+    an empty proposal 16 B."""
+    W = 8 * ((n + 63) // 64)
+    return (int(d["sum_k"]) + 4 * int(d["n_flip"]) + 8 * int(d["n_dmove"])) * W \
+        + 64 * int(d["n_flip"]) + 128 * int(d["n_dmove"]) + 16 * int(d["n_empty"])
+
+
+def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
+    """Times the CPU oracle (reference-faithful port: neighbourhood lookup,
+    induced-subgraph recount before/after, revert from saved vectors) on the
+    host cores, one chain per thread, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_ffi as oracle  # checker / baseline only, never the product path
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    go = oracle.Graph.from_edges(n, edges)
+    bo = oracle.Bounds.from_lists(*bounds_lists)
+    probe = oracle.Chain(go, bo, seed=seed, chain_id=0)
+    t0 = time.perf_counter()
+    probe.step(2000)
+    per_prop = (time.perf_counter() - t0) / 2000
+    nprop = max(1000, int(target_seconds / per_prop))
+    chains = [oracle.Chain(go, bo, seed=seed, chain_id=c) for c in range(cores)]
+    secs = oracle.chains_step_mt(chains, nprop, cores)
+    total = nprop * cores
+    return {"value": total / secs, "unit": "proposals/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d proposals of the same n=%d graph, seeds as GPU chains 0..%d, %.1f s"
+                      % (cores, nprop, n, cores - 1, secs),
+            "single_thread_proposals_per_s": 1.0 / per_prop}
+
+
+def load_traffic(n_chains, proposals):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same
+    command (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        rec = json.load(open(path))
+        if rec.get("n_chains") == n_chains and rec.get("proposals") == proposals:
+            return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
+    ap.add_argument("--proposals", type=int, default=1024, help="proposals per chain per step")
+    ap.add_argument("--n", type=int, default=1000)
+    ap.add_argument("--p", type=float, default=0.10)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import flag_complex_mcmc_amd as fcm
+    from flag_complex_mcmc_amd import distributed as fdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available() or fcm.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libfcm has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # ---- workload: synthetic ER digraph, same on every rank ---------------------
+    edges = fcm.graphs.random_with_p(args.n, args.p, args.seed)
+    g = fcm.Graph.from_edges(args.n, edges)
+    flag_count = g.flagser_count(local_rank)
+    bounds = fcm.Bounds.calculate(g, flag_count, fcm.Bounds.target(flag_count, 0.01), device=local_rank)
+    total_chains = args.chains * world                      # weak scaling: fixed chains per GPU
+    lo, hi = fdist.shard_range(total_chains, rank, world)
+    s = fcm.MCMCSampler(g, bounds, n_chains=hi - lo, seed=args.seed, move_weights=fcm.MOVE_DISTRIBUTION_SIMPLE,
+                        device=local_rank, first_chain_id=lo)
+    s.set_stream(torch.cuda.current_stream().cuda_stream)   # so torch events bracket the kernel's own stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        s.step(args.proposals, sync=False)
+    torch.cuda.synchronize()
+    st0 = s.stats()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        s.step(args.proposals, sync=False)
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # avg launch duration, HIP events on the launch stream
+
+    # report-time exchange: gather the per-chain count histograms over RCCL
+    st1 = s.stats()
+    counts = s.flag_counts()
+    stat_mat = np.stack([st1[k] for k in fcm._ffi.STAT_NAMES], axis=1)
+    all_counts, all_stats = fdist.gather_counts(counts, stat_mat, device=dev)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- parity gate on this rank's result (outside the timed region) ----------
+    d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k")}
+    assert d["sampled"] == (hi - lo) * args.steps * args.proposals, "proposal count mismatch"
+    for c in (0, (hi - lo) // 2, hi - lo - 1):
+        assert s.graph(c).flagser_count(local_rank) == s.flag_count(c), "incremental counts != full recount (chain %d)" % c
+        assert bounds.check(s.flag_count(c)), "chain %d left the bounds" % c
+
+    if rank == 0:
+        total_prop = total_chains * args.steps * args.proposals
+        abytes = algorithmic_bytes(d, args.n) / args.steps          # per launch, this rank
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": METRIC, "value": total_prop / elapsed, "unit": "proposals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32/u64 bitset", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Erdos-Renyi digraph n=%d p=%.2f seed %d, %d chains per GPU, "
+                                   "%d proposals per chain per step, --simple moves [0.5,0.5,0,0], target_relaxation 0.01"
+                                   % (args.n, args.p, args.seed, args.chains, args.proposals),
+                       "n": args.n, "p": args.p, "chains_per_gpu": args.chains, "proposals_per_step": args.proposals,
+                       "edges": int(len(edges)), "initial_flag_count": flag_count, "parallelism": "chains sharded, %d rank(s)" % world},
+            "per_gpu_value": total_prop / elapsed / world,
+            "kernel_ms_per_launch": kernel_ms,
+            "accept_ratio": float(d["accepted"]) / float(d["sampled"]),
+            "empty_fraction": float(d["n_empty"]) / float(d["sampled"]),
+            "mean_k": float(d["sum_k"]) / max(1.0, float(d["n_flip"] + 2 * d["n_dmove"])),
+            "count_histogram_dim2_distinct": int(len(fdist.count_histogram(all_counts, 2)[0])),
+            "parity": "counts == full GPU recount on 3 chains; oracle parity in tests/ -m gpu",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_traffic(args.chains, args.proposals),
+                         "algorithmic_bytes_per_launch": abytes, "kernel": "fcm_step_kernel"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.n, edges, (bounds.flag_count_min, bounds.flag_count_max), args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

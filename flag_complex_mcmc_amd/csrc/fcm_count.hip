@@ -1,0 +1,152 @@
+// fcm_count.hip — global simplex count kernel, the row-broadcast kernel and
+// the launch dispatchers.
+#include "fcm_kernels_common.hpp"
+
+// ---------------------------------------------------------------------------
+// Global count: flagser_count.  One wave per directed edge u->v (grid-stride):
+// the simplices whose first two vertices are u, v have their remaining
+// vertices in C = out(u) & out(v); count directed simplices inside C.
+// ---------------------------------------------------------------------------
+#define FCM_COUNT_MAXT 14   // dims up to 15
+#define FCM_COUNT_MAXNW 4   // |C| <= 256
+
+template <int NW>
+__device__ __forceinline__ void count_local(const u32 *rows, u32 stride32, const u32 *Lc, int total, u64 *Hs, int lane,
+                                            int (&delta)[FCM_COUNT_MAXT + 1], u32 &overflow)
+{
+    u32 Lv[NW];
+#pragma unroll
+    for (int g = 0; g < NW; ++g) Lv[g] = (g * 64 + lane < total) ? Lc[g * 64 + lane] : 0u;
+    Mask<NW> myH[NW];
+    build_local<NW>(rows, stride32, Lv, total, lane, myH);
+    store_local<NW>(Hs, myH, lane);
+    wave_sync();
+    Classes<NW> cls;
+    cls.P = m_zero<NW>();
+    cls.M = m_zero<NW>();
+#pragma unroll
+    for (int g = 0; g < NW; ++g) {
+        const int rem = total - 64 * g;
+        cls.S.w[g] = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
+    }
+    eval_classes<FCM_COUNT_MAXT, NW, true>(myH, Hs, cls, FCM_COUNT_MAXT, +1, lane, delta, overflow);
+    wave_sync();
+}
+
+__global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
+{
+    constexpr int MAXNW = FCM_COUNT_MAXNW;
+    __shared__ u64 Hs[WAVE * MAXNW * MAXNW];
+    __shared__ u32 Lc[WAVE * MAXNW];
+    const int lane = threadIdx.x;
+    const u32 nwords = (p.n + 31u) >> 5;
+    u64 acc[FCM_COUNT_MAXT + 1];
+#pragma unroll
+    for (int q = 0; q <= FCM_COUNT_MAXT; ++q) acc[q] = 0ull;
+    u32 overflow = 0, toolarge = 0;
+
+    for (u64 e = blockIdx.x; e < p.m; e += gridDim.x) {
+        const u32 u = p.edges[2 * e], v = p.edges[2 * e + 1];
+        const u32 *ru = p.rows + (size_t)u * p.stride32;
+        const u32 *rv = p.rows + (size_t)v * p.stride32;
+        u32 total = 0;
+        for (u32 w0 = 0; w0 < nwords; w0 += WAVE) {
+            const u32 w = w0 + lane;
+            u32 x = (w < nwords) ? (ru[w] & rv[w]) : 0u;
+            const u32 c = __popc(x);
+            u32 inc = c;  // inclusive scan over the wave
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const u32 y = __shfl_up(inc, o, WAVE);
+                if (lane >= o) inc += y;
+            }
+            const u32 tot = rdlane(inc, WAVE - 1);
+            u32 pos = total + inc - c;
+            while (x) {
+                const u32 b = __ffs((int)x) - 1;
+                x &= x - 1;
+                if (pos < WAVE * MAXNW) Lc[pos] = w * 32u + b;
+                ++pos;
+            }
+            total += tot;
+        }
+        if (total == 0) continue;
+        if (total > WAVE * MAXNW) { toolarge = 1u; continue; }
+        wave_sync();
+        int delta[FCM_COUNT_MAXT + 1];
+#pragma unroll
+        for (int q = 0; q <= FCM_COUNT_MAXT; ++q) delta[q] = 0;
+        FCM_DISPATCH_NW((int)total,
+            (count_local<1>(p.rows, p.stride32, Lc, (int)total, Hs, lane, delta, overflow)),
+            (count_local<2>(p.rows, p.stride32, Lc, (int)total, Hs, lane, delta, overflow)),
+            (count_local<4>(p.rows, p.stride32, Lc, (int)total, Hs, lane, delta, overflow)));
+#pragma unroll
+        for (int q = 1; q <= FCM_COUNT_MAXT; ++q) acc[q] += (u64)(u32)delta[q];
+        wave_sync();
+    }
+#pragma unroll
+    for (int q = 1; q <= FCM_COUNT_MAXT; ++q) {
+        const u64 s = (u64)wave_sum_i64((long long)acc[q]);
+        if (lane == 0 && s) atomicAdd((unsigned long long *)&p.counts[q + 1], (unsigned long long)s);
+    }
+    if (ballot(toolarge != 0u) && lane == 0) atomicOr(&p.flags[0], 1u);
+    if (ballot(overflow != 0u) && lane == 0) atomicOr(&p.flags[1], 1u);
+}
+
+// rows[c] = base for every chain c; 16 B per lane, coalesced.
+__global__ __launch_bounds__(256) void fcm_broadcast_rows_kernel(uint4 *__restrict__ rows, const uint4 *__restrict__ base,
+                                                               u64 vec_per_chain, u32 nchains)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < vec_per_chain; i += stride) {
+        const uint4 v = base[i];
+        for (u32 c = 0; c < nchains; ++c) rows[(u64)c * vec_per_chain + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+extern "C" {
+int fcm_launch_step_6_1(const FcmStepParams *, void *);
+int fcm_launch_step_6_2(const FcmStepParams *, void *);
+int fcm_launch_step_6_4(const FcmStepParams *, void *);
+int fcm_launch_step_14_1(const FcmStepParams *, void *);
+int fcm_launch_step_14_2(const FcmStepParams *, void *);
+int fcm_launch_step_14_4(const FcmStepParams *, void *);
+}
+
+// maxt: 6 (<= 8 count entries) or 14; maxnw: 1, 2 or 4 mask words (local sets <= 64 / 128 / 256)
+extern "C" int fcm_launch_step(const FcmStepParams *p, int maxt, int maxnw, void *stream)
+{
+    if (maxt <= 6) {
+        if (maxnw <= 1) return fcm_launch_step_6_1(p, stream);
+        if (maxnw <= 2) return fcm_launch_step_6_2(p, stream);
+        return fcm_launch_step_6_4(p, stream);
+    }
+    if (maxnw <= 1) return fcm_launch_step_14_1(p, stream);
+    if (maxnw <= 2) return fcm_launch_step_14_2(p, stream);
+    return fcm_launch_step_14_4(p, stream);
+}
+extern "C" int fcm_launch_count(const FcmCountParams *p, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (p->m == 0) return 0;
+    const u64 maxgrid = 256ull * 32ull;
+    dim3 grid((unsigned)(p->m < maxgrid ? p->m : maxgrid)), block(WAVE);
+    hipLaunchKernelGGL(fcm_count_kernel, grid, block, 0, st, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fcm_launch_broadcast_rows(uint32_t *rows, const uint32_t *base, uint64_t words_per_chain,
+                                         uint32_t nchains, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const u64 vec = words_per_chain / 4;  // rows are 128-B multiples
+    u64 blocks = (vec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(fcm_broadcast_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       (uint4 *)rows, (const uint4 *)base, vec, nchains);
+    return (int)hipGetLastError();
+}

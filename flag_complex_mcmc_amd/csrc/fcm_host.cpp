@@ -274,7 +274,7 @@ static int device_count(const uint32_t *rows, uint32_t n, uint32_t stride32, con
         HIP_TRY(hipMemcpy(dc, d_counts.p, sizeof dc, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost));
         if (flags[0])
-            return fail(FCM_ERR_UNSUPPORTED, "an edge has more than %d common out-neighbours; not supported by this build", FCM_MAX_LOCAL);
+            return fail(FCM_ERR_UNSUPPORTED, "a directed edge has more than %d common out-neighbours; not supported by this build", FCM_MAX_LOCAL);
         if (flags[1])
             return fail(FCM_ERR_UNSUPPORTED, "graph holds simplices of dimension > %d", FCM_MAX_COUNTS - 1);
         for (int d = 2; d < FCM_MAX_COUNTS; ++d) counts[d] = dc[d];
@@ -531,7 +531,7 @@ struct fcm_sampler {
     fcm_sampler_config cfg{};
     fcm_sampler_info info{};
     FcmStepParams params{};
-    int maxt_variant = 6;
+    int maxt_variant = 6, maxnw_variant = 1;
     uint32_t n = 0, stride32 = 0;
     std::vector<uint32_t> ue;          // [U][2] big, small
     // device buffers
@@ -618,6 +618,7 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     }
     if (kmax + 2 > FCM_MAX_LOCAL)
         return fail(FCM_ERR_UNSUPPORTED, "an edge has %u common neighbours; this build supports at most %d", kmax, FCM_MAX_LOCAL - 2);
+    s->maxnw_variant = kmax + 2 <= 64 ? 1 : (kmax + 2 <= 128 ? 2 : 4);
     const uint64_t D = dbl0.size();
 
     // --- initial counts and the reachable dimension range ------------------
@@ -746,7 +747,7 @@ extern "C" int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals)
     while (left > 0) {
         const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
         s->params.nprop = chunk;
-        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->stream);
+        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->maxnw_variant, s->stream);
         if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
         left -= chunk;
     }

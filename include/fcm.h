@@ -41,9 +41,10 @@ extern "C" {
  * undirected clique number exceeds 16 are refused unless a dim_cap is given. */
 #define FCM_MAX_COUNTS 16
 
-/* Largest |N(a) cap N(b)| + 2 the step kernel supports (one 64-lane wave holds
- * one local vertex per lane). */
-#define FCM_MAX_LOCAL 64
+/* Largest local vertex set (|N(a) cap N(b)| + 2 for a move, |out(u) cap out(v)|
+ * for the counter) the kernels support: one 64-lane wave holds up to four
+ * local vertices per lane. */
+#define FCM_MAX_LOCAL 256
 
 typedef uint32_t fcm_node;     /* reference `Node` = u32 (src/flagser.rs:5,9) */
 

@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py -- chain sharding and the
+report-time gather of per-chain count histograms."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_chains():
+    from flag_complex_mcmc_amd.distributed import shard_range
+    for total, world in [(8192, 8), (2048, 8), (10, 4), (3, 8), (4096, 1)]:
+        got = []
+        for r in range(world):
+            lo, hi = shard_range(total, r, world)
+            assert 0 <= lo <= hi <= total
+            got += list(range(lo, hi))
+        assert got == list(range(total))
+    assert shard_range(8192, 3, 8) == (3072, 4096)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    from flag_complex_mcmc_amd.distributed import shard_range, gather_counts, count_histogram
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    total, nc, ns = 12, 6, 8
+    lo, hi = shard_range(total, rank, world)
+    # chain c holds counts c*10+d (with a value above 2^63 to check the u64 bit pattern survives)
+    counts = np.array([[c * 10 + d for d in range(nc)] for c in range(lo, hi)], np.uint64)
+    counts[:, 2] += np.uint64(2**63)
+    stats = np.array([[c * 100 + j for j in range(ns)] for c in range(lo, hi)], np.uint64)
+    ac, ast = gather_counts(counts, stats)
+    assert ac.shape == (total, nc) and ast.shape == (total, ns), (ac.shape, ast.shape)
+    want = np.array([[c * 10 + d for d in range(nc)] for c in range(total)], np.uint64)
+    want[:, 2] += np.uint64(2**63)
+    assert (ac == want).all()
+    assert (ast[:, 0] == np.arange(total) * 100).all()
+    vals, mult = count_histogram(ac, 3)
+    assert len(vals) == total and mult.sum() == total
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_gather_counts_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_gather_is_identity_without_process_group():
+    from flag_complex_mcmc_amd.distributed import gather_counts
+    c = np.arange(12, dtype=np.uint64).reshape(3, 4)
+    s = np.arange(24, dtype=np.uint64).reshape(3, 8)
+    ac, ast = gather_counts(c, s)
+    assert (ac == c).all() and (ast == s).all()

@@ -238,11 +238,61 @@ def test_unsupported_inputs_fail_loudly(fcm):
     assert ei.value.code == 4
     with pytest.raises(fcm.FcmError):
         fcm.MCMCSampler(g, b, move_weights=(0, 0, 0, 0))
-    # a dense graph whose common neighbourhoods exceed one wave
-    big = fcm.Graph.from_edges(80, graphs.simplex(79))
+    # more reachable dimensions than the 16 tracked count entries
+    big = fcm.Graph.from_edges(20, graphs.simplex(19))
     with pytest.raises(fcm.FcmError) as ei:
-        fcm.MCMCSampler(big, fcm.Bounds([80], [80]))
+        fcm.MCMCSampler(big, fcm.Bounds([20], [20]))
     assert ei.value.code == 4
+    # a common neighbourhood beyond 254 vertices (4 mask words per lane)
+    t = 300
+    book = [(0, 1)] + [(0, w) for w in range(2, t)] + [(1, w) for w in range(2, t)]
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MCMCSampler(fcm.Graph.from_edges(t, book), fcm.Bounds([t], [t]))
+    assert ei.value.code == 4
+
+
+def _book_graph(t, p_page, seed):
+    """Edge {0,1} whose common neighbourhood is every other vertex ("pages"),
+    random orientations, sparse random edges among the pages: local sets of
+    t vertices with low dimension -- exercises the multi-word mask paths."""
+    rng = np.random.default_rng(seed)
+    e = [(0, 1)]
+    for w in range(2, t):
+        for a in (0, 1):
+            r = rng.random()
+            if r < 0.45:
+                e.append((a, w))
+            elif r < 0.9:
+                e.append((w, a))
+            else:
+                e += [(a, w), (w, a)]
+    for i in range(2, t):
+        for j in range(2, t):
+            if i != j and rng.random() < p_page:
+                e.append((i, j))
+    return np.array(e, np.uint32)
+
+
+@pytest.mark.parametrize("t,p_page", [(66, 0.04), (100, 0.03), (129, 0.02), (200, 0.012)])
+def test_wide_neighbourhoods(fcm, oracle, t, p_page):
+    """|N(a) cap N(b)| + 2 = t > 64: two or four mask words per local vertex."""
+    e = _book_graph(t, p_page, seed=t)
+    go = oracle.Graph.from_edges(t, e)
+    assert fcm.Graph.from_edges(t, e).flagser_count() == go.flagser_count()
+    s, tw = _run_parity(fcm, oracle, t, e, n_chains=2, steps=[64, 2000], seed=t, relaxation=0.3)
+    assert s.info["k_max"] == t - 2
+    st = s.stats()
+    assert (st["n_flip"] > 0).all() and (st["n_dmove"] > 0).all()
+
+
+def test_count_wide_common_out_neighbourhood(fcm, oracle):
+    # 0->1, 0->w, 1->w for 200 pages: out(0) & out(1) has 200 vertices
+    t = 202
+    e = [(0, 1)] + [(0, w) for w in range(2, t)] + [(1, w) for w in range(2, t)]
+    rng = np.random.default_rng(0)
+    e += [(int(i), int(j)) for i in range(2, t) for j in range(2, t) if i != j and rng.random() < 0.02]
+    e = np.array(e, np.uint32)
+    assert fcm.Graph.from_edges(t, e).flagser_count() == oracle.Graph.from_edges(t, e).flagser_count()
 
 
 # -------------------------------------------------- edgebits (src/io.rs) -----
