@@ -39,6 +39,7 @@ def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_ffi as oracle  # checker / baseline only, never the product path
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("FCM_BENCH_CPU_THREADS", "16"))))  # a 1-GPU box's CPU share is 16
     go = oracle.Graph.from_edges(n, edges)
     bo = oracle.Bounds.from_lists(*bounds_lists)
     probe = oracle.Chain(go, bo, seed=seed, chain_id=0)
@@ -46,6 +47,7 @@ def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
     probe.step(2000)
     per_prop = (time.perf_counter() - t0) / 2000
     nprop = max(1000, int(target_seconds / per_prop))
+    log("cpu baseline: %.1f us/proposal single thread; %d threads x %d proposals" % (per_prop * 1e6, cores, nprop))
     chains = [oracle.Chain(go, bo, seed=seed, chain_id=c) for c in range(cores)]
     secs = oracle.chains_step_mt(chains, nprop, cores)
     total = nprop * cores
@@ -66,6 +68,13 @@ def load_traffic(n_chains, proposals):
     except Exception:
         pass
     return None
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
 
 
 def main():
@@ -104,13 +113,18 @@ def main():
     # ---- workload: synthetic ER digraph, same on every rank ---------------------
     edges = fcm.graphs.random_with_p(args.n, args.p, args.seed)
     g = fcm.Graph.from_edges(args.n, edges)
+    log("graph built: %d edges" % len(edges))
     flag_count = g.flagser_count(local_rank)
+    log("initial count %s" % flag_count)
     bounds = fcm.Bounds.calculate(g, flag_count, fcm.Bounds.target(flag_count, 0.01), device=local_rank)
     total_chains = args.chains * world                      # weak scaling: fixed chains per GPU
     lo, hi = fdist.shard_range(total_chains, rank, world)
     s = fcm.MCMCSampler(g, bounds, n_chains=hi - lo, seed=args.seed, move_weights=fcm.MOVE_DISTRIBUTION_SIMPLE,
                         device=local_rank, first_chain_id=lo)
-    s.set_stream(torch.cuda.current_stream().cuda_stream)   # so torch events bracket the kernel's own stream
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    s.set_stream(stream.cuda_stream)   # kernels and the timing events share this one HIP stream
+    log("sampler ready: %s" % s.info)
 
     def barrier():
         if world > 1:
@@ -119,6 +133,7 @@ def main():
     for _ in range(args.warmup):
         s.step(args.proposals, sync=False)
     torch.cuda.synchronize()
+    log("warmup done")
     st0 = s.stats()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -134,6 +149,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # avg launch duration, HIP events on the launch stream
+    log("timed region done: %.3f s, %.2f ms per launch" % (elapsed, kernel_ms))
 
     # report-time exchange: gather the per-chain count histograms over RCCL
     st1 = s.stats()
@@ -149,8 +165,14 @@ def main():
     # ---- parity gate on this rank's result (outside the timed region) ----------
     d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k")}
     assert d["sampled"] == (hi - lo) * args.steps * args.proposals, "proposal count mismatch"
+    def strip(v):  # flag_count never shrinks in length (src/lib.rs:72-74): ignore trailing zeros
+        v = list(v)
+        while v and v[-1] == 0:
+            v.pop()
+        return v
+
     for c in (0, (hi - lo) // 2, hi - lo - 1):
-        assert s.graph(c).flagser_count(local_rank) == s.flag_count(c), "incremental counts != full recount (chain %d)" % c
+        assert s.graph(c).flagser_count(local_rank) == strip(s.flag_count(c)), "incremental counts != full recount (chain %d)" % c
         assert bounds.check(s.flag_count(c)), "chain %d left the bounds" % c
 
     if rank == 0:

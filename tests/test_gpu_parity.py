@@ -340,7 +340,10 @@ def test_full_size_config3_invariants(fcm):
     und0 = fcm.Graph.from_edges(n, e).undirected_edges()
     for c in (0, 100, 255):
         g = s.graph(c)
-        assert g.flagser_count() == s.flag_count(c)
+        fc = s.flag_count(c)
+        while fc[-1] == 0:   # flag_count never shrinks in length (src/lib.rs:72-74)
+            fc.pop()
+        assert g.flagser_count() == fc
         assert (g.undirected_edges() == und0).all() and g.nedges() == len(e)
         assert s.bounds.check(s.flag_count(c))
     assert (counts[:, 0] == n).all() and (counts[:, 1] == len(e)).all()
