@@ -5,39 +5,18 @@
 // ---------------------------------------------------------------------------
 // Global count: flagser_count.  One wave per directed edge u->v (grid-stride):
 // the simplices whose first two vertices are u, v have their remaining
-// vertices in C = out(u) & out(v); count directed simplices inside C.
+// vertices in C = out(u) & out(v); count directed simplices inside C (all of
+// class S: every vertex comes after v).
 // ---------------------------------------------------------------------------
 #define FCM_COUNT_MAXT 14   // dims up to 15
 #define FCM_COUNT_MAXNW 4   // |C| <= 256
 
-template <int NW>
-__device__ __forceinline__ void count_local(const u32 *rows, u32 stride32, const u32 *Lc, int total, u64 *Hs, int lane,
-                                            int (&delta)[FCM_COUNT_MAXT + 1], u32 &overflow)
-{
-    u32 Lv[NW];
-#pragma unroll
-    for (int g = 0; g < NW; ++g) Lv[g] = (g * 64 + lane < total) ? Lc[g * 64 + lane] : 0u;
-    Mask<NW> myH[NW];
-    build_local<NW>(rows, stride32, Lv, total, lane, myH);
-    store_local<NW>(Hs, myH, lane);
-    wave_sync();
-    Classes<NW> cls;
-    cls.P = m_zero<NW>();
-    cls.M = m_zero<NW>();
-#pragma unroll
-    for (int g = 0; g < NW; ++g) {
-        const int rem = total - 64 * g;
-        cls.S.w[g] = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
-    }
-    eval_classes<FCM_COUNT_MAXT, NW, true>(myH, Hs, cls, FCM_COUNT_MAXT, +1, lane, delta, overflow);
-    wave_sync();
-}
-
 __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
 {
-    constexpr int MAXNW = FCM_COUNT_MAXNW;
-    __shared__ u64 Hs[WAVE * MAXNW * MAXNW];
-    __shared__ u32 Lc[WAVE * MAXNW];
+    extern __shared__ u64 smem[];  // fcm_lds_words(FCM_COUNT_MAXNW)
+    const Wide W = wide_carve(smem, FCM_COUNT_MAXNW);
+    u64 *Hs = smem;      // fast path: 64 masks
+    u32 *Lc = W.L;       // candidate list, both paths
     const int lane = threadIdx.x;
     const u32 nwords = (p.n + 31u) >> 5;
     u64 acc[FCM_COUNT_MAXT + 1];
@@ -65,23 +44,45 @@ __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
             while (x) {
                 const u32 b = __ffs((int)x) - 1;
                 x &= x - 1;
-                if (pos < WAVE * MAXNW) Lc[pos] = w * 32u + b;
+                if (pos < WAVE * FCM_COUNT_MAXNW) Lc[pos] = w * 32u + b;
                 ++pos;
             }
             total += tot;
         }
         if (total == 0) continue;
-        if (total > WAVE * MAXNW) { toolarge = 1u; continue; }
+        if (total > WAVE * FCM_COUNT_MAXNW) { toolarge = 1u; continue; }
         wave_sync();
-        int delta[FCM_COUNT_MAXT + 1];
+        if (total <= WAVE) {
+            const u32 Lv = lane < (int)total ? Lc[lane] : 0u;
+            const u64 myH = build_local(p.rows, p.stride32, Lv, (int)total, lane);
+            wave_sync();
+            Hs[lane] = myH;
+            wave_sync();
+            int delta[FCM_COUNT_MAXT + 1];
 #pragma unroll
-        for (int q = 0; q <= FCM_COUNT_MAXT; ++q) delta[q] = 0;
-        FCM_DISPATCH_NW((int)total,
-            (count_local<1>(p.rows, p.stride32, Lc, (int)total, Hs, lane, delta, overflow)),
-            (count_local<2>(p.rows, p.stride32, Lc, (int)total, Hs, lane, delta, overflow)),
-            (count_local<4>(p.rows, p.stride32, Lc, (int)total, Hs, lane, delta, overflow)));
+            for (int q = 0; q <= FCM_COUNT_MAXT; ++q) delta[q] = 0;
+            const u64 S = total >= 64 ? ~0ull : ((1ull << total) - 1ull);
+            eval_classes<FCM_COUNT_MAXT, true>(myH, Hs, 0ull, 0ull, S, FCM_COUNT_MAXT, +1, lane, delta, overflow);
 #pragma unroll
-        for (int q = 1; q <= FCM_COUNT_MAXT; ++q) acc[q] += (u64)(u32)delta[q];
+            for (int q = 1; q <= FCM_COUNT_MAXT; ++q) acc[q] += (u64)(u32)delta[q];
+        } else {
+            Wide V = W;
+            V.NW = (int)((total + 63u) >> 6);
+            wide_zero_counts(V, lane);
+            wide_build(V, p.rows, p.stride32, (int)total, lane);
+            if (lane < 12) V.cls[lane] = 0ull;
+            wave_sync();
+            if (lane < V.NW) {
+                const int rem = (int)total - 64 * lane;
+                V.cls[2 * 4 + lane] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+            }
+            wave_sync();
+            wide_dfs<true>(V, FCM_COUNT_MAXT, +1, &overflow);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 1; q <= FCM_COUNT_MAXT; ++q) acc[q] += (u64)V.cnt[q];
+            }
+        }
         wave_sync();
     }
 #pragma unroll
@@ -108,33 +109,23 @@ __global__ __launch_bounds__(256) void fcm_broadcast_rows_kernel(uint4 *__restri
 // Launchers
 // ---------------------------------------------------------------------------
 extern "C" {
-int fcm_launch_step_6_1(const FcmStepParams *, void *);
-int fcm_launch_step_6_2(const FcmStepParams *, void *);
-int fcm_launch_step_6_4(const FcmStepParams *, void *);
-int fcm_launch_step_14_1(const FcmStepParams *, void *);
-int fcm_launch_step_14_2(const FcmStepParams *, void *);
-int fcm_launch_step_14_4(const FcmStepParams *, void *);
+int fcm_launch_step_6(const FcmStepParams *, void *);
+int fcm_launch_step_14(const FcmStepParams *, void *);
 }
 
-// maxt: 6 (<= 8 count entries) or 14; maxnw: 1, 2 or 4 mask words (local sets <= 64 / 128 / 256)
-extern "C" int fcm_launch_step(const FcmStepParams *p, int maxt, int maxnw, void *stream)
+// maxt: 6 (<= 8 count entries) or 14
+extern "C" int fcm_launch_step(const FcmStepParams *p, int maxt, void *stream)
 {
-    if (maxt <= 6) {
-        if (maxnw <= 1) return fcm_launch_step_6_1(p, stream);
-        if (maxnw <= 2) return fcm_launch_step_6_2(p, stream);
-        return fcm_launch_step_6_4(p, stream);
-    }
-    if (maxnw <= 1) return fcm_launch_step_14_1(p, stream);
-    if (maxnw <= 2) return fcm_launch_step_14_2(p, stream);
-    return fcm_launch_step_14_4(p, stream);
+    return maxt <= 6 ? fcm_launch_step_6(p, stream) : fcm_launch_step_14(p, stream);
 }
+
 extern "C" int fcm_launch_count(const FcmCountParams *p, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (p->m == 0) return 0;
     const u64 maxgrid = 256ull * 32ull;
     dim3 grid((unsigned)(p->m < maxgrid ? p->m : maxgrid)), block(WAVE);
-    hipLaunchKernelGGL(fcm_count_kernel, grid, block, 0, st, *p);
+    hipLaunchKernelGGL(fcm_count_kernel, grid, block, sizeof(u64) * fcm_lds_words(FCM_COUNT_MAXNW), st, *p);
     return (int)hipGetLastError();
 }
 

@@ -35,6 +35,7 @@ struct FcmStepParams {
     uint64_t rows_per_chain;   // n * stride32 (u32 words)
     uint32_t n, stride32, U, D, dbl_stride, first_chain, nchains;
     int32_t ncounts;           // tracked count entries NC (<= 16)
+    int32_t maxnw;             // mask words the largest local set needs: ceil((k_max+2)/64), 1..4
 };
 
 struct FcmCountParams {
@@ -50,7 +51,7 @@ struct FcmCountParams {
 extern "C" {
 #endif
 // launchers implemented in fcm_kernels.hip; `stream` is a hipStream_t
-int fcm_launch_step(const FcmStepParams *p, int maxt, int maxnw, void *stream);
+int fcm_launch_step(const FcmStepParams *p, int maxt, void *stream);
 int fcm_launch_count(const FcmCountParams *p, void *stream);
 int fcm_launch_broadcast_rows(uint32_t *rows, const uint32_t *base, uint64_t words_per_chain, uint32_t nchains, void *stream);
 #ifdef __cplusplus

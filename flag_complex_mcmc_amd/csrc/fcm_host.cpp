@@ -703,6 +703,7 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     p.first_chain = cfg->first_chain_id;
     p.nchains = C;
     p.ncounts = nc;
+    p.maxnw = s->maxnw_variant;
 
     if (s->cfg.sample_distance == 0) s->cfg.sample_distance = fcm_default_sample_distance(fc[1]);  // sample.rs:102
 
@@ -747,7 +748,7 @@ extern "C" int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals)
     while (left > 0) {
         const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
         s->params.nprop = chunk;
-        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->maxnw_variant, s->stream);
+        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->stream);
         if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
         left -= chunk;
     }

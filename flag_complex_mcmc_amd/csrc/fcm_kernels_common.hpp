@@ -1,6 +1,6 @@
-// fcm_kernels_common.hpp — gfx950 (MI355X, CDNA4) kernels for the edge-flip MCMC hot
-// path of flag-complex-mcmc.  64-wide wavefronts throughout; integer bitset
-// work only (no MFMA).
+// fcm_kernels_common.hpp — gfx950 (MI355X, CDNA4) device code for the edge-flip
+// MCMC hot path of flag-complex-mcmc.  64-wide wavefronts throughout; integer
+// bitset work only (no MFMA).
 //
 //   fcm_step_kernel   one persistent 64-lane workgroup per chain.  Runs
 //                     `nprop` iterations of the reference loop
@@ -10,21 +10,27 @@
 //                     (Bounds::check, :157-160), commit or drop (:187-191).
 //   fcm_count_kernel  flagser_count (src/lib.rs:51,130; src/flagser.rs:9):
 //                     one wave per directed edge, simplices that start with
-//                     that edge.
+//                     that edge.  (fcm_count.hip)
 //
 // How a proposal is counted.  The reference recounts the whole induced
 // subgraph on N(a) cap N(b) + {a,b} before and after (src/lib.rs:63,71); only
 // post - pre matters.  Every simplex that differs contains
 // the changed directed edge, so the kernel counts exactly those:
 //   E(G, u->v)[d] = #d-simplices of G that contain the edge u->v.
-// removing an edge subtracts E before removal, adding one adds E after.
+// Removing an edge subtracts E before removal, adding one adds E after.
 // All vertices of such a simplex lie in L = N(u) cap N(v) + {u,v} (static,
-// src/lib.rs:330).  The wave builds the induced out-adjacency of L as one
-// 64-bit mask per local vertex (lane j tests bit L[j] of row L[i]; the
-// v_cmp result *is* the ballot), stages the masks in LDS, classifies each
-// w in L by where it can sit relative to u->v (P: w->u,w->v  M: u->w,w->v
-// S: u->w,v->w) and runs a per-lane DFS (lane = first vertex) over mask
-// intersections with popcounts at the leaves.
+// src/lib.rs:330).  The wave builds the induced out-adjacency of L as bit
+// masks over local indices (lane j tests bit L[j] of row L[i]; the v_cmp
+// result *is* the ballot), stages the masks in LDS, classifies each w in L by
+// where it can sit relative to u->v (P: w->u,w->v  M: u->w,w->v  S: u->w,v->w)
+// and walks the simplices by mask intersection with popcounts at the leaves.
+//
+// Two evaluators share that scheme:
+//   fast  |L| <= 64: one 64-bit mask per local vertex; per-lane DFS in
+//         registers (lane = first vertex), depth unrolled at compile time.
+//   wide  |L| <= 256 (rare: a handful of edges in the BASELINE graphs):
+//         masks of NW <= 4 words; one wave-uniform DFS with its stack in LDS.
+//         Register-light on purpose, so that it costs the fast path nothing.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -70,181 +76,44 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
 // Single-wave workgroup: orders LDS/global traffic between lanes of the wave.
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
-// ---------------------------------------------------------------------------
-// Local vertex sets and masks.  A local set of s vertices uses NW = ceil(s/64)
-// 64-bit words per mask; lane l owns local vertices l, l+64, ... (one per
-// "group" g < NW).  NW is a template parameter, every loop over it is
-// unrolled and every index into a per-lane array is a compile-time constant
-// (runtime-indexed register arrays would go to scratch).
-// ---------------------------------------------------------------------------
-template <int NW> struct Mask { u64 w[NW]; };
+// ===========================================================================
+// Fast evaluator: local sets of <= 64 vertices, one u64 mask per vertex
+// ===========================================================================
 
-template <int NW> __device__ __forceinline__ Mask<NW> m_zero()
+// Induced out-adjacency of the local vertex set.  Lane j (< s) holds local
+// vertex Lv.  Returns this lane's out-mask over local indices 0..s-1.  One
+// dword per lane per row: bit L[j] of row L[i].  Rows are 128-B multiples, so
+// one row-read is one or few cache lines, shared by the 64 lanes.
+#define FCM_HB 16  // rows in flight per batch
+__device__ __forceinline__ u64 build_local(const u32 *rows, u32 stride32, u32 Lv, int s, int lane)
 {
-    Mask<NW> r;
+    const bool act = lane < s;
+    const u32 woff = act ? (Lv >> 5) : 0u;
+    const u32 bit = Lv & 31u;
+    u64 myH = 0;
+    for (int i0 = 0; i0 < s; i0 += FCM_HB) {
+        u32 w[FCM_HB];
 #pragma unroll
-    for (int g = 0; g < NW; ++g) r.w[g] = 0ull;
-    return r;
-}
-template <int NW> __device__ __forceinline__ Mask<NW> m_and(const Mask<NW> &a, const Mask<NW> &b)
-{
-    Mask<NW> r;
+        for (int q = 0; q < FCM_HB; ++q) {
+            const int i = min(i0 + q, s - 1);
+            const u32 vi = rdlane(Lv, i);
+            w[q] = rows[(size_t)vi * stride32 + woff];
+        }
 #pragma unroll
-    for (int g = 0; g < NW; ++g) r.w[g] = a.w[g] & b.w[g];
-    return r;
-}
-template <int NW> __device__ __forceinline__ Mask<NW> m_or(const Mask<NW> &a, const Mask<NW> &b)
-{
-    Mask<NW> r;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) r.w[g] = a.w[g] | b.w[g];
-    return r;
-}
-template <int NW> __device__ __forceinline__ bool m_any(const Mask<NW> &a)
-{
-    u64 r = 0;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) r |= a.w[g];
-    return r != 0ull;
-}
-template <int NW> __device__ __forceinline__ int m_popc(const Mask<NW> &a)
-{
-    int r = 0;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) r += __popcll(a.w[g]);
-    return r;
-}
-// bit `idx` (runtime) of a
-template <int NW> __device__ __forceinline__ bool m_test(const Mask<NW> &a, int idx)
-{
-    u64 w = a.w[0];
-#pragma unroll
-    for (int g = 1; g < NW; ++g) w = ((idx >> 6) == g) ? a.w[g] : w;
-    return (w >> (idx & 63)) & 1ull;
-}
-template <int NW> __device__ __forceinline__ void m_assign_bit(Mask<NW> &a, int idx, bool val)
-{
-    const u64 bit = 1ull << (idx & 63);
-#pragma unroll
-    for (int g = 0; g < NW; ++g)
-        if ((idx >> 6) == g) a.w[g] = val ? (a.w[g] | bit) : (a.w[g] & ~bit);
-}
-// remove and return the lowest set bit (a must be non-empty); one call site
-// regardless of NW, straight-line selects
-template <int NW> __device__ __forceinline__ int m_pop_lowest(Mask<NW> &a)
-{
-    int x = 0;
-    bool done = false;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) {
-        const bool take = !done && a.w[g] != 0ull;
-        x = take ? (g * 64 + __ffsll((long long)a.w[g]) - 1) : x;
-        a.w[g] = take ? (a.w[g] & (a.w[g] - 1ull)) : a.w[g];
-        done = done || take;
-    }
-    return x;
-}
-template <int NW> __device__ __forceinline__ Mask<NW> lds_row(const u64 *Hs, int x)
-{
-    Mask<NW> r;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) r.w[g] = Hs[x * NW + g];
-    return r;
-}
-
-// ---------------------------------------------------------------------------
-// Induced out-adjacency of the local vertex set.  Lane l holds local vertices
-// Lv[g] (index g*64+l, valid while < s).  On return myH[g] is the out-mask of
-// local vertex g*64+l over local indices 0..s-1.  One dword per lane per row
-// and word: bit L[j] of row L[i]; the v_cmp result *is* the ballot.  Rows are
-// 128-B multiples, so one row-read is one or few cache lines shared by the wave.
-// ---------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ void build_local(const u32 *rows, u32 stride32, const u32 (&Lv)[NW], int s, int lane,
-                                            Mask<NW> (&myH)[NW])
-{
-    constexpr int HB = 16 / NW;  // rows per batch: 16 loads in flight
-    bool act[NW];
-    u32 woff[NW], bit[NW];
-#pragma unroll
-    for (int g = 0; g < NW; ++g) {
-        act[g] = g * 64 + lane < s;
-        woff[g] = act[g] ? (Lv[g] >> 5) : 0u;
-        bit[g] = Lv[g] & 31u;
-        myH[g] = m_zero<NW>();
-    }
-#pragma unroll
-    for (int gi = 0; gi < NW; ++gi) {
-        const int cnt = min(64, s - 64 * gi);
-        for (int i0 = 0; i0 < cnt; i0 += HB) {
-            u32 w[HB][NW];
-#pragma unroll
-            for (int q = 0; q < HB; ++q) {
-                const int i = min(i0 + q, cnt - 1);
-                const u32 vi = rdlane(Lv[gi], i);
-                const u32 *row = rows + (size_t)vi * stride32;
-#pragma unroll
-                for (int gj = 0; gj < NW; ++gj) w[q][gj] = row[woff[gj]];
-            }
-#pragma unroll
-            for (int q = 0; q < HB; ++q) {
-#pragma unroll
-                for (int gj = 0; gj < NW; ++gj) {
-                    const u64 m = ballot(act[gj] && ((w[q][gj] >> bit[gj]) & 1u));
-                    if (lane == i0 + q) myH[gi].w[gj] = m;
-                }
-            }
+        for (int q = 0; q < FCM_HB; ++q) {
+            const u64 m = ballot(act && ((w[q] >> bit) & 1u));
+            if (lane == i0 + q) myH = m;
         }
     }
-#pragma unroll
-    for (int g = 0; g < NW; ++g)
-        if (!act[g]) myH[g] = m_zero<NW>();
+    return act ? myH : 0ull;
 }
 
-template <int NW>
-__device__ __forceinline__ void store_local(u64 *Hs, const Mask<NW> (&myH)[NW], int lane)
-{
-#pragma unroll
-    for (int g = 0; g < NW; ++g)
-#pragma unroll
-        for (int q = 0; q < NW; ++q) Hs[(g * 64 + lane) * NW + q] = myH[g].w[q];
-}
-
-// set / clear the local edge i -> j in the lane copy (the LDS copy is rewritten by store_local)
-template <int NW>
-__device__ __forceinline__ void local_set_edge(Mask<NW> (&myH)[NW], int lane, int i, int j, bool present)
-{
-#pragma unroll
-    for (int g = 0; g < NW; ++g)
-        if (lane == (i & 63) && (i >> 6) == g) m_assign_bit<NW>(myH[g], j, present);
-}
-
-// ---------------------------------------------------------------------------
 // Per-lane DFS.  A node has T vertices of K chosen, `cand` = common
 // out-neighbours still allowed (non-empty, already restricted to classes
 // >= ph).  Children with class ph2 >= ph each add one simplex with T+1
 // K-vertices.  delta[t] accumulates sign * (#simplices with t K-vertices).
-// ---------------------------------------------------------------------------
-template <int NW> struct Classes { Mask<NW> P, M, S; };
-
-template <int NW> __device__ __forceinline__ Mask<NW> cls_mask(const Classes<NW> &c, int ph)
-{
-    Mask<NW> r;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) r.w[g] = ph == 0 ? c.P.w[g] : (ph == 1 ? c.M.w[g] : c.S.w[g]);
-    return r;
-}
-template <int NW> __device__ __forceinline__ Mask<NW> cls_ge(const Classes<NW> &c, int ph)
-{
-    Mask<NW> r;
-#pragma unroll
-    for (int g = 0; g < NW; ++g)
-        r.w[g] = ph == 0 ? (c.P.w[g] | c.M.w[g] | c.S.w[g]) : (ph == 1 ? (c.M.w[g] | c.S.w[g]) : c.S.w[g]);
-    return r;
-}
-
-template <int T, int MAXT, int NW, bool DETECT>
-__device__ __forceinline__ void dfs_level(const Mask<NW> &cand, int ph, const u64 *Hs, const Classes<NW> &cls,
+template <int T, int MAXT, bool DETECT>
+__device__ __forceinline__ void dfs_level(u64 cand, int ph, const u64 *Hs, u64 P, u64 M, u64 S,
                                           int tmax, int sign, int (&delta)[MAXT + 1], u32 &overflow)
 {
     if constexpr (T < MAXT) {
@@ -252,15 +121,16 @@ __device__ __forceinline__ void dfs_level(const Mask<NW> &cand, int ph, const u6
             const bool deeper = DETECT || (T + 2 <= tmax);
 #pragma nounroll
             for (int ph2 = ph; ph2 < 3; ++ph2) {
-                Mask<NW> c = m_and<NW>(cand, cls_mask<NW>(cls, ph2));
-                delta[T + 1] += sign * m_popc<NW>(c);
+                const u64 cm = ph2 == 0 ? P : (ph2 == 1 ? M : S);
+                u64 c = cand & cm;
+                delta[T + 1] += sign * __popcll(c);
                 if (deeper) {
-                    const Mask<NW> ge = cls_ge<NW>(cls, ph2);
-                    while (m_any<NW>(c)) {
-                        const int x = m_pop_lowest<NW>(c);
-                        const Mask<NW> nc = m_and<NW>(m_and<NW>(cand, lds_row<NW>(Hs, x)), ge);
-                        if (m_any<NW>(nc))
-                            dfs_level<T + 1, MAXT, NW, DETECT>(nc, ph2, Hs, cls, tmax, sign, delta, overflow);
+                    const u64 ge = ph2 == 0 ? (P | M | S) : (ph2 == 1 ? (M | S) : S);
+                    while (c) {
+                        const int x = __ffsll((long long)c) - 1;
+                        c &= c - 1;
+                        const u64 nc = cand & Hs[x] & ge;
+                        if (nc) dfs_level<T + 1, MAXT, DETECT>(nc, ph2, Hs, P, M, S, tmax, sign, delta, overflow);
                     }
                 }
             }
@@ -273,22 +143,19 @@ __device__ __forceinline__ void dfs_level(const Mask<NW> &cand, int ph, const u6
 }
 
 // Count simplices through the classified local set.  Lane = first K-vertex.
-template <int MAXT, int NW, bool DETECT>
-__device__ __forceinline__ void eval_classes(const Mask<NW> (&myH)[NW], const u64 *Hs, const Classes<NW> &cls,
-                                             int tmax, int sign, int lane, int (&delta)[MAXT + 1], u32 &overflow)
+template <int MAXT, bool DETECT>
+__device__ __forceinline__ void eval_classes(u64 myH, const u64 *Hs, u64 P, u64 M, u64 S, int tmax, int sign,
+                                             int lane, int (&delta)[MAXT + 1], u32 &overflow)
 {
-#pragma unroll
-    for (int g = 0; g < NW; ++g) {
-        const u32 cb = (u32)((cls.P.w[g] >> lane) & 1ull) | ((u32)((cls.M.w[g] >> lane) & 1ull) << 1) |
-                       ((u32)((cls.S.w[g] >> lane) & 1ull) << 2);
-        if (tmax >= 1) delta[1] += sign * __popc(cb);
-        if (cb && tmax >= 2) {
+    const u32 cb = (u32)((P >> lane) & 1ull) | ((u32)((M >> lane) & 1ull) << 1) | ((u32)((S >> lane) & 1ull) << 2);
+    if (tmax >= 1) delta[1] += sign * __popc(cb);
+    if (cb && tmax >= 2) {
 #pragma nounroll
-            for (int ph = 0; ph < 3; ++ph) {
-                if ((cb >> ph) & 1u) {
-                    const Mask<NW> nc = m_and<NW>(myH[g], cls_ge<NW>(cls, ph));
-                    if (m_any<NW>(nc)) dfs_level<1, MAXT, NW, DETECT>(nc, ph, Hs, cls, tmax, sign, delta, overflow);
-                }
+        for (int ph = 0; ph < 3; ++ph) {
+            if ((cb >> ph) & 1u) {
+                const u64 ge = ph == 0 ? (P | M | S) : (ph == 1 ? (M | S) : S);
+                const u64 nc = myH & ge;
+                if (nc) dfs_level<1, MAXT, DETECT>(nc, ph, Hs, P, M, S, tmax, sign, delta, overflow);
             }
         }
     }
@@ -296,65 +163,47 @@ __device__ __forceinline__ void eval_classes(const Mask<NW> (&myH)[NW], const u6
 
 // E(G, u->v) on the local set: iu, iv = local indices of u and v; the edge
 // u->v must be present in Hs / myH.
-template <int MAXT, int NW>
-__device__ __forceinline__ void eval_edge(const Mask<NW> (&myH)[NW], const u64 *Hs, int iu, int iv, int tmax, int sign,
-                                          int lane, int (&delta)[MAXT + 1])
+template <int MAXT>
+__device__ __forceinline__ void eval_edge(u64 myH, const u64 *Hs, int iu, int iv, int tmax, int sign, int lane,
+                                          int (&delta)[MAXT + 1])
 {
-    const Mask<NW> outU = lds_row<NW>(Hs, iu), outV = lds_row<NW>(Hs, iv);
-    Classes<NW> cls;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) {
-        const u64 inU = ballot(m_test<NW>(myH[g], iu)), inV = ballot(m_test<NW>(myH[g], iv));
-        u64 nbm = ~0ull;
-        if ((iu >> 6) == g) nbm &= ~(1ull << (iu & 63));
-        if ((iv >> 6) == g) nbm &= ~(1ull << (iv & 63));
-        cls.P.w[g] = inU & inV & nbm;            // w->u, w->v : before u
-        cls.M.w[g] = outU.w[g] & inV & nbm;      // u->w, w->v : between
-        cls.S.w[g] = outU.w[g] & outV.w[g] & nbm;  // u->w, v->w : after v
-    }
+    const u64 outU = Hs[iu], outV = Hs[iv];
+    const u64 inU = ballot((myH >> iu) & 1ull), inV = ballot((myH >> iv) & 1ull);
+    const u64 nbm = ~((1ull << iu) | (1ull << iv));
+    const u64 P = inU & inV & nbm;    // w->u, w->v : before u
+    const u64 M = outU & inV & nbm;   // u->w, w->v : between
+    const u64 S = outU & outV & nbm;  // u->w, v->w : after v
     u32 dummy = 0;
-    eval_classes<MAXT, NW, false>(myH, Hs, cls, tmax, sign, lane, delta, dummy);
+    eval_classes<MAXT, false>(myH, Hs, P, M, S, tmax, sign, lane, delta, dummy);
 }
 
-// local vertex list of undirected edge (big, small): K then big, small
-template <int NW>
-__device__ __forceinline__ void load_local_list(const u32 *nb, u32 off, int k, u32 big, u32 small, int lane, u32 (&Lv)[NW])
-{
-#pragma unroll
-    for (int g = 0; g < NW; ++g) {
-        const int j = g * 64 + lane;
-        Lv[g] = j < k ? nb[off + j] : (j == k ? big : small);
-    }
-}
+// ---- the three evaluations a simple move is made of (fast path) -------------
+// K then big, small: lane k = big, lane k+1 = small.
 
-// ---- the three evaluations a simple move is made of ------------------------
-// single_edge_flip on undirected edge e=(big,small): returns 0 if the pair is
+// single_edge_flip on undirected edge (big,small): returns 0 if the pair is
 // reciprocal (empty transition), 1 if big->small was flipped, 2 if small->big,
 // -1 if the bitmap disagrees with the static table.
-template <int MAXT, int NW>
+template <int MAXT>
 __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
                                          u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
-    u32 Lv[NW];
-    load_local_list<NW>(nb, off, k, big, small, lane, Lv);
-    Mask<NW> myH[NW];
-    build_local<NW>(rows, stride32, Lv, s, lane, myH);
-    store_local<NW>(Hs, myH, lane);
+    const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
+    u64 myH = build_local(rows, stride32, Lv, s, lane);
+    Hs[lane] = myH;
     wave_sync();
-    const bool ab = m_test<NW>(lds_row<NW>(Hs, k), k + 1), ba = m_test<NW>(lds_row<NW>(Hs, k + 1), k);
+    const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
     int res;
     if (ab == ba) {
         res = ab ? 0 : -1;
     } else {
         const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;  // u->v present
-        eval_edge<MAXT, NW>(myH, Hs, iu, iv, tmax, -1, lane, delta);
-        local_set_edge<NW>(myH, lane, iu, iv, false);
-        local_set_edge<NW>(myH, lane, iv, iu, true);
+        eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta);
         wave_sync();
-        store_local<NW>(Hs, myH, lane);
+        if (lane == iu) { myH &= ~(1ull << iv); Hs[lane] = myH; }
+        if (lane == iv) { myH |= (1ull << iu); Hs[lane] = myH; }
         wave_sync();
-        eval_edge<MAXT, NW>(myH, Hs, iv, iu, tmax, +1, lane, delta);
+        eval_edge<MAXT>(myH, Hs, iv, iu, tmax, +1, lane, delta);
         res = ab ? 1 : 2;
     }
     wave_sync();
@@ -364,74 +213,308 @@ __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u3
 // double_edge_move step 1: subtract the simplices through one direction of the
 // reciprocal pair (big,small).  coin=1 removes big->small.  Returns false if
 // the pair is not reciprocal in the bitmap.
-template <int MAXT, int NW>
+template <int MAXT>
 __device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
                                          u32 coin, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
-    u32 Lv[NW];
-    load_local_list<NW>(nb, off, k, big, small, lane, Lv);
-    Mask<NW> myH[NW];
-    build_local<NW>(rows, stride32, Lv, s, lane, myH);
-    store_local<NW>(Hs, myH, lane);
+    const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
+    const u64 myH = build_local(rows, stride32, Lv, s, lane);
+    Hs[lane] = myH;
     wave_sync();
-    const bool ab = m_test<NW>(lds_row<NW>(Hs, k), k + 1), ba = m_test<NW>(lds_row<NW>(Hs, k + 1), k);
+    const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
     const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
-    eval_edge<MAXT, NW>(myH, Hs, iu, iv, tmax, -1, lane, delta);
+    eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta);
     wave_sync();
-    return ab && ba;
+    return (ab & ba) != 0u;
 }
 
 // double_edge_move step 2: on the graph without dfrom->dto, add the reverse of
 // the single edge of (big,small) and add the simplices through it.  fwd=1
 // means big->small is the existing direction.
-template <int MAXT, int NW>
+template <int MAXT>
 __device__ __forceinline__ void add_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
                                          u32 fwd, u32 dfrom, u32 dto, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
-    u32 Lv[NW];
-    load_local_list<NW>(nb, off, k, big, small, lane, Lv);
-    Mask<NW> myH[NW];
-    build_local<NW>(rows, stride32, Lv, s, lane, myH);
-    // the pending removal, if both its endpoints are local
-    int fi = -1, ti = -1;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) {
-        const bool act = g * 64 + lane < s;
-        const u64 mf = ballot(act && Lv[g] == dfrom), mt = ballot(act && Lv[g] == dto);
-        if (mf) fi = g * 64 + __ffsll((long long)mf) - 1;
-        if (mt) ti = g * 64 + __ffsll((long long)mt) - 1;
+    const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
+    u64 myH = build_local(rows, stride32, Lv, s, lane);
+    const bool act = lane < s;
+    const u64 mf = ballot(act && Lv == dfrom), mt = ballot(act && Lv == dto);
+    if (mf && mt) {  // the pending removal, if both its endpoints are local
+        const int fi = __ffsll((long long)mf) - 1, ti = __ffsll((long long)mt) - 1;
+        if (lane == fi) myH &= ~(1ull << ti);
     }
-    if (fi >= 0 && ti >= 0) local_set_edge<NW>(myH, lane, fi, ti, false);
     const int ia = fwd ? k : k + 1, ib = fwd ? k + 1 : k;  // a->b exists, add b->a
-    local_set_edge<NW>(myH, lane, ib, ia, true);
-    store_local<NW>(Hs, myH, lane);
+    if (lane == ib) myH |= (1ull << ia);
+    Hs[lane] = myH;
     wave_sync();
-    eval_edge<MAXT, NW>(myH, Hs, ib, ia, tmax, +1, lane, delta);
+    eval_edge<MAXT>(myH, Hs, ib, ia, tmax, +1, lane, delta);
     wave_sync();
 }
 
-// dispatch on the local set size (wave-uniform)
-#define FCM_DISPATCH_NW(S_, CALL1, CALL2, CALL4)                 \
-    do {                                                         \
-        if ((S_) <= 64) { CALL1; }                               \
-        else if constexpr (MAXNW >= 2) {                         \
-            if ((S_) <= 128) { CALL2; }                          \
-            else if constexpr (MAXNW >= 4) { CALL4; }            \
-        }                                                        \
-    } while (0)
+// ===========================================================================
+// Wide evaluator: local sets of 65..256 vertices, NW = ceil(s/64) mask words.
+// Everything is wave-uniform: all lanes run the same DFS on the same values
+// (masks live in LDS, the current frame in registers), so there is no per-lane
+// stack and the register cost is a few dozen VGPRs whatever NW is.
+// ===========================================================================
+#define FCM_WIDE_LEVELS 16
+struct Wide {
+    u64 *H;        // [s][NW] out-masks of the local vertices
+    u64 *cls;      // [3][4]  P, M, S
+    u64 *stk;      // [FCM_WIDE_LEVELS][2][4]  saved (cand, rem) frames
+    long long *cnt;  // [16] signed simplex counts by number of K-vertices
+    int *stkph;    // [FCM_WIDE_LEVELS][2]     saved (ph, ph2)
+    u32 *L;        // [64*NW] local vertex ids
+    int NW;
+};
+// u64 words of dynamic LDS a workgroup needs for local sets of up to 64*NW vertices
+__host__ __device__ inline unsigned fcm_lds_words(int NW)
+{
+    if (NW <= 1) return 64u;
+    return 64u * NW * NW + 12u + FCM_WIDE_LEVELS * 8u + 16u + FCM_WIDE_LEVELS + 32u * NW;
+}
+__device__ __forceinline__ Wide wide_carve(u64 *smem, int NW)
+{
+    Wide W;
+    W.NW = NW;
+    W.H = smem;
+    W.cls = W.H + 64 * NW * NW;
+    W.stk = W.cls + 12;
+    W.cnt = (long long *)(W.stk + FCM_WIDE_LEVELS * 8);
+    W.stkph = (int *)(W.cnt + 16);
+    W.L = (u32 *)(W.stkph + 2 * FCM_WIDE_LEVELS);
+    return W;
+}
 
-// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wide_zero_counts(const Wide &W, int lane)
+{
+    if (lane < 16) W.cnt[lane] = 0;
+    wave_sync();
+}
+
+// Induced out-adjacency into W.H; the vertex list is already in W.L[0..s).
+__device__ __forceinline__ void wide_build(const Wide W, const u32 *rows, u32 stride32, int s, int lane)
+{
+    const int NW = W.NW;
+    bool act[4];
+    u32 woff[4], bit[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int j = g * 64 + lane;
+        act[g] = g < NW && j < s;
+        const u32 lv = act[g] ? W.L[j] : 0u;
+        woff[g] = lv >> 5;
+        bit[g] = lv & 31u;
+    }
+    for (int i0 = 0; i0 < s; i0 += 4) {
+        u32 w[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 vi = W.L[min(i0 + q, s - 1)];
+            const u32 *row = rows + (size_t)vi * stride32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[q][g] = act[g] ? row[woff[g]] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u64 m = ballot(act[g] && ((w[q][g] >> bit[g]) & 1u));
+                if (g < NW && i0 + q < s) W.H[(i0 + q) * NW + g] = m;  // every lane writes the same value
+            }
+        }
+    }
+    wave_sync();
+}
+
+__device__ __forceinline__ bool wide_has(const Wide &W, int i, int j) { return (W.H[i * W.NW + (j >> 6)] >> (j & 63)) & 1ull; }
+__device__ __forceinline__ void wide_set(const Wide &W, int i, int j, bool present)
+{
+    u64 &w = W.H[i * W.NW + (j >> 6)];
+    const u64 b = 1ull << (j & 63);
+    w = present ? (w | b) : (w & ~b);  // uniform read-modify-write, same value from every lane
+}
+
+// Uniform DFS over the classified local set (classes in W.cls).  Adds
+// sign * (#simplices with t K-vertices) to W.cnt[t].
+template <bool DETECT>
+__device__ __forceinline__ void wide_dfs(const Wide W, int tmax, int sign, u32 *overflow)
+{
+    const int NW = W.NW;
+    if (tmax < 1) return;
+    u64 cand[4], rem[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        cand[g] = g < NW ? (W.cls[0 * 4 + g] | W.cls[1 * 4 + g] | W.cls[2 * 4 + g]) : 0ull;
+        rem[g] = 0ull;
+    }
+    int ph = 0, ph2 = -1, level = 0;
+    for (;;) {
+        if ((rem[0] | rem[1] | rem[2] | rem[3]) == 0ull) {
+            ph2 = max(ph2 + 1, ph);
+            if (ph2 > 2) {  // node exhausted: back to the parent
+                if (level == 0) break;
+                --level;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    cand[g] = W.stk[(level * 2 + 0) * 4 + g];
+                    rem[g] = W.stk[(level * 2 + 1) * 4 + g];
+                }
+                ph = W.stkph[2 * level];
+                ph2 = W.stkph[2 * level + 1];
+                continue;
+            }
+            int pc = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                rem[g] = g < NW ? (cand[g] & W.cls[ph2 * 4 + g]) : 0ull;
+                pc += __popcll(rem[g]);
+            }
+            W.cnt[level + 1] += (long long)sign * pc;
+            if (!(DETECT || level + 2 <= tmax)) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rem[g] = 0ull;
+            }
+            continue;
+        }
+        // next child x of class ph2
+        int x = 0;
+        bool done = false;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bool take = !done && rem[g] != 0ull;
+            x = take ? (g * 64 + __ffsll((long long)rem[g]) - 1) : x;
+            rem[g] = take ? (rem[g] & (rem[g] - 1ull)) : rem[g];
+            done = done || take;
+        }
+        u64 nc[4], any = 0ull;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u64 ge = 0ull;
+            if (g < NW) {
+                ge = W.cls[2 * 4 + g];
+                if (ph2 <= 1) ge |= W.cls[1 * 4 + g];
+                if (ph2 == 0) ge |= W.cls[0 * 4 + g];
+                nc[g] = cand[g] & W.H[x * NW + g] & ge;
+            } else {
+                nc[g] = 0ull;
+            }
+            any |= nc[g];
+        }
+        if (any) {
+            if (level + 2 <= tmax && level + 1 < FCM_WIDE_LEVELS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    W.stk[(level * 2 + 0) * 4 + g] = cand[g];
+                    W.stk[(level * 2 + 1) * 4 + g] = rem[g];
+                    cand[g] = nc[g];
+                    rem[g] = 0ull;
+                }
+                W.stkph[2 * level] = ph;
+                W.stkph[2 * level + 1] = ph2;
+                ++level;
+                ph = ph2;
+                ph2 = ph - 1;
+            } else if (DETECT) {
+                *overflow = 1u;  // simplices deeper than the tracked dimensions exist
+            }
+        }
+    }
+    wave_sync();
+}
+
+// classes of every local vertex relative to the edge iu->iv, into W.cls
+__device__ __forceinline__ void wide_classify(const Wide W, int iu, int iv, int s, int lane)
+{
+    const int NW = W.NW;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < NW) {
+            const int j = g * 64 + lane;
+            const bool a = j < s;
+            const u64 inU = ballot(a && wide_has(W, a ? j : 0, iu)), inV = ballot(a && wide_has(W, a ? j : 0, iv));
+            const u64 outU = W.H[iu * NW + g], outV = W.H[iv * NW + g];
+            u64 nbm = ~0ull;
+            if ((iu >> 6) == g) nbm &= ~(1ull << (iu & 63));
+            if ((iv >> 6) == g) nbm &= ~(1ull << (iv & 63));
+            W.cls[0 * 4 + g] = inU & inV & nbm;
+            W.cls[1 * 4 + g] = outU & inV & nbm;
+            W.cls[2 * 4 + g] = outU & outV & nbm;
+        }
+    }
+    wave_sync();
+}
+
+__device__ __forceinline__ void wide_load_list(const Wide &W, const u32 *nb, u32 off, int k, u32 big, u32 small, int lane)
+{
+    for (int j = lane; j < k + 2; j += WAVE) W.L[j] = j < k ? nb[off + j] : (j == k ? big : small);
+    wave_sync();
+}
+
+// The wide twins of flip_eval / del_eval / add_eval.  Results go to W.cnt.
+__device__ __forceinline__ int wide_flip(const Wide W, const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big,
+                                      u32 small, int lane, int tmax)
+{
+    const int s = k + 2;
+    wide_load_list(W, nb, off, k, big, small, lane);
+    wide_build(W, rows, stride32, s, lane);
+    const bool ab = wide_has(W, k, k + 1), ba = wide_has(W, k + 1, k);
+    if (ab == ba) return ab ? 0 : -1;
+    const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;
+    wide_classify(W, iu, iv, s, lane);
+    wide_dfs<false>(W, tmax, -1, nullptr);
+    wide_set(W, iu, iv, false);
+    wide_set(W, iv, iu, true);
+    wave_sync();
+    wide_classify(W, iv, iu, s, lane);
+    wide_dfs<false>(W, tmax, +1, nullptr);
+    return ab ? 1 : 2;
+}
+__device__ __forceinline__ bool wide_del(const Wide W, const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big,
+                                      u32 small, u32 coin, int lane, int tmax)
+{
+    const int s = k + 2;
+    wide_load_list(W, nb, off, k, big, small, lane);
+    wide_build(W, rows, stride32, s, lane);
+    const bool ab = wide_has(W, k, k + 1), ba = wide_has(W, k + 1, k);
+    const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
+    wide_classify(W, iu, iv, s, lane);
+    wide_dfs<false>(W, tmax, -1, nullptr);
+    return ab && ba;
+}
+__device__ __forceinline__ void wide_add(const Wide W, const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big,
+                                      u32 small, u32 fwd, u32 dfrom, u32 dto, int lane, int tmax)
+{
+    const int s = k + 2;
+    wide_load_list(W, nb, off, k, big, small, lane);
+    wide_build(W, rows, stride32, s, lane);
+    int fi = -1, ti = -1;
+    for (int g = 0; g < W.NW; ++g) {
+        const int j = g * 64 + lane;
+        const u32 lv = j < s ? W.L[j] : 0xFFFFFFFFu;
+        const u64 mf = ballot(j < s && lv == dfrom), mt = ballot(j < s && lv == dto);
+        if (mf) fi = g * 64 + __ffsll((long long)mf) - 1;
+        if (mt) ti = g * 64 + __ffsll((long long)mt) - 1;
+    }
+    if (fi >= 0 && ti >= 0) wide_set(W, fi, ti, false);
+    const int ia = fwd ? k : k + 1, ib = fwd ? k + 1 : k;
+    wide_set(W, ib, ia, true);
+    wave_sync();
+    wide_classify(W, ib, ia, s, lane);
+    wide_dfs<false>(W, tmax, +1, nullptr);
+}
+
+// ===========================================================================
 // Step kernel
-// ---------------------------------------------------------------------------
-// MINW = minimum waves per SIMD the register allocator must leave room for
-// (4 => at most 128 VGPRs; the rare wide-neighbourhood paths then spill instead
-// of costing every chain its residency).
-template <int MAXT, int MAXNW, int MINW>
+// ===========================================================================
+// MINW = minimum waves per SIMD the register allocator must leave room for.
+template <int MAXT, int MINW>
 __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParams p)
 {
-    __shared__ u64 Hs[WAVE * MAXNW * MAXNW];
+    extern __shared__ u64 smem[];  // fcm_lds_words(p.maxnw) words
+    u64 *Hs = smem;
     const int lane = threadIdx.x;
     const u32 chain = blockIdx.x;
     if (chain >= p.nchains) return;
@@ -459,6 +542,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     const u32 k0 = (u32)p.seed, k1 = (u32)(p.seed >> 32);
     const u32 gchain = p.first_chain + chain;
     const u32 stride32 = p.stride32;
+    const int maxnw = p.maxnw;
 
     // is the current state inside the bounds?  (decides whether an empty
     // transition is "accepted", src/lib.rs:186-187)
@@ -486,7 +570,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 #pragma unroll
             for (int q = 0; q <= MAXT; ++q) delta[q] = 0;
 
-            bool nonempty = false;
+            bool nonempty = false, used_wide = false;
             // pending commit (uniform)
             u32 c_clr_from = 0, c_clr_to = 0, c_set_from = 0, c_set_to = 0;
             u32 c_slot = 0, c_newdbl = 0;
@@ -498,11 +582,17 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     const u32 a = rdlane(l_e.big, sidx), b = rdlane(l_e.small, sidx);
                     const u32 off = rdlane(l_e.nb_off, sidx);
                     const int k = (int)rdlane(l_e.k, sidx);
-                    int res = 0;
-                    FCM_DISPATCH_NW(k + 2,
-                        (res = flip_eval<MAXT, 1>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta)),
-                        (res = flip_eval<MAXT, 2>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta)),
-                        (res = flip_eval<MAXT, 4>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta)));
+                    int res;
+                    if (k + 2 <= WAVE) {
+                        res = flip_eval<MAXT>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta);
+                    } else if (k + 2 <= 64 * maxnw) {
+                        const Wide W = wide_carve(smem, maxnw);
+                        wide_zero_counts(W, lane);
+                        res = wide_flip(W, rows, stride32, nb, off, k, a, b, lane, tmax);
+                        used_wide = true;
+                    } else {
+                        res = -1;
+                    }
                     if (res < 0) status |= 1u;  // table says adjacent, bitmap says not
                     if (res > 0) {
                         nonempty = true;
@@ -517,25 +607,32 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     const u32 slot = (u32)idx;
                     const u32 ed = dbl[slot];
                     const FcmEdgeEntry de = p.etab[ed];
-                    // 64 candidate draws for the single edge, first valid wins
-                    // (uniform directed edge, retry while reciprocal: :308-313)
+                    // Up to 64 candidate draws for the single edge, first valid wins
+                    // (uniform directed edge, retry while reciprocal: :308-313).
                     const u64 tt = sampled;  // this proposal's step index
                     u32 v[4];
                     philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(lane >> 1) + 1u, k0, k1, v);
                     const u64 y64 = (lane & 1) ? ((u64)v[2] | ((u64)v[3] << 32)) : ((u64)v[0] | ((u64)v[1] << 32));
                     const u64 rr = __umul64hi(y64, Mtot);
-                    bool valid = rr < U;
+                    // Probe the candidates four at a time (lanes base..base+3): one
+                    // is valid with probability ~0.9, so later groups are almost never
+                    // touched and the probe costs a dozen cache lines, not two hundred.
+                    // The winner is the first valid candidate in lane order either way.
                     FcmEdgeEntry ce = {0u, 0u, 0u, 0u};
                     u32 fwd = 0;
-                    if (valid) {
-                        ce = p.etab[rr];
-                        const u32 wf = rows[(size_t)ce.big * stride32 + (ce.small >> 5)];
-                        const u32 wb = rows[(size_t)ce.small * stride32 + (ce.big >> 5)];
-                        fwd = (wf >> (ce.small & 31u)) & 1u;
-                        const u32 bwd = (wb >> (ce.big & 31u)) & 1u;
-                        valid = (fwd ^ bwd) != 0u;
+                    u64 vm = 0ull;
+                    for (int base = 0; base < WAVE && vm == 0ull; base += 4) {
+                        bool valid = lane >= base && lane < base + 4 && rr < U;
+                        if (valid) {
+                            ce = p.etab[rr];
+                            const u32 wf = rows[(size_t)ce.big * stride32 + (ce.small >> 5)];
+                            const u32 wb = rows[(size_t)ce.small * stride32 + (ce.big >> 5)];
+                            fwd = (wf >> (ce.small & 31u)) & 1u;
+                            const u32 bwd = (wb >> (ce.big & 31u)) & 1u;
+                            valid = (fwd ^ bwd) != 0u;
+                        }
+                        vm = ballot(valid);
                     }
-                    const u64 vm = ballot(valid);
                     if (vm) {
                         const int first = __ffsll((long long)vm) - 1;
                         const u32 r = (u32)rdlane64(rr, first);
@@ -547,19 +644,26 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         // delme: coin ? (big->small) : (small->big) of the reciprocal pair (:316-320)
                         const u32 dfrom = coin ? de.big : de.small, dto = coin ? de.small : de.big;
                         nonempty = true; is_dmove = true;
-                        // (1) remove delme: subtract simplices through it
-                        bool okd = true;
                         const int dk = (int)de.k;
-                        FCM_DISPATCH_NW(dk + 2,
-                            (okd = del_eval<MAXT, 1>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta)),
-                            (okd = del_eval<MAXT, 2>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta)),
-                            (okd = del_eval<MAXT, 4>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta)));
+                        const bool any_wide = dk + 2 > WAVE || rk + 2 > WAVE;
+                        bool okd = true;
+                        if (any_wide) {
+                            if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
+                                status |= 1u;
+                            } else {
+                                const Wide W = wide_carve(smem, maxnw);
+                                wide_zero_counts(W, lane);
+                                okd = wide_del(W, rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, lane, tmax);
+                                wide_add(W, rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, lane, tmax);
+                                used_wide = true;
+                            }
+                        } else {
+                            // (1) remove delme: subtract simplices through it
+                            okd = del_eval<MAXT>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta);
+                            // (2) add eb->ea on the graph without delme: add simplices through it
+                            add_eval<MAXT>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta);
+                        }
                         if (!okd) status |= 2u;  // slot list says reciprocal, bitmap says not
-                        // (2) add eb->ea on the graph without delme: add simplices through it
-                        FCM_DISPATCH_NW(rk + 2,
-                            (add_eval<MAXT, 1>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta)),
-                            (add_eval<MAXT, 2>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta)),
-                            (add_eval<MAXT, 4>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta)));
                         c_clr_from = dfrom; c_clr_to = dto;
                         c_set_from = eb; c_set_to = ea;
                         c_slot = slot; c_newdbl = r;
@@ -578,11 +682,17 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             } else {
                 if (is_dmove) n_dmove += 1; else n_flip += 1;
                 long long myd = 0;
+                if (used_wide) {
+                    const Wide W = wide_carve(smem, maxnw);
+                    if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = W.cnt[lane - 1];
+                    wave_sync();
+                } else {
 #pragma unroll
-                for (int tq = 1; tq <= MAXT; ++tq) {
-                    if (tq <= tmax) {
-                        const long long sum = wave_sum_i64((long long)delta[tq]);
-                        if (lane == tq + 1) myd = sum;
+                    for (int tq = 1; tq <= MAXT; ++tq) {
+                        if (tq <= tmax) {
+                            const long long sum = wave_sum_i64((long long)delta[tq]);
+                            if (lane == tq + 1) myd = sum;
+                        }
                     }
                 }
                 const u64 ncnt = cnt + (u64)myd;
@@ -615,4 +725,3 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         st_g[4] = n_dmove; st_g[5] = sum_k; st_g[6] = count_len; st_g[7] = status;
     }
 }
-
