@@ -65,12 +65,38 @@ __device__ __forceinline__ u64 rdlane64(u64 v, int l)
     return (u64)rdlane((u32)v, l) | ((u64)rdlane((u32)(v >> 32), l) << 32);
 }
 __device__ __forceinline__ u64 ballot(bool p) { return __ballot(p); }
+// v_writelane_b32: lane `l` of `old` := the wave-uniform value `src`
+__device__ __forceinline__ u32 wrlane(u32 src, int l, u32 old)
+{
+#if __has_builtin(__builtin_amdgcn_writelane)
+    return (u32)__builtin_amdgcn_writelane((int)src, l, (int)old);
+#else
+    // two SGPR sources would break the constant-bus limit: the lane select goes through m0
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(src), "s"(l) : "m0");
+    return old;
+#endif
+}
 
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
+}
+
+// Sum of a 32-bit value over the wave with DPP adds (no LDS): prefix sums
+// inside each row of 16 lanes (row_shr 1,2,4,8), then row_bcast:15 / :31 carry
+// the row totals upward.  The total lands in lane 63 and is returned uniform.
+// Per-proposal local simplex counts are far below 2^31.
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Single-wave workgroup: orders LDS/global traffic between lanes of the wave.
@@ -85,27 +111,56 @@ __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 // dword per lane per row: bit L[j] of row L[i].  Rows are 128-B multiples, so
 // one row-read is one or few cache lines, shared by the 64 lanes.
 #define FCM_HB 16  // rows in flight per batch
-__device__ __forceinline__ u64 build_local(const u32 *rows, u32 stride32, u32 Lv, int s, int lane)
+__device__ int g_dbg_dummy;
+#define g_dbg (dbg_flags)
+__device__ __forceinline__ u64 build_local_(const u32 *rows, u32 stride32, u32 Lv, int s, int lane);
+__device__ __forceinline__ u64 build_local_dbg(const u32 *rows, u32 stride32, u32 Lv, int s, int lane, int dbg_flags)
+{
+    if (g_dbg & 2) return lane < s ? ((u64)Lv * 0x9E3779B97F4A7C15ull) & ((s >= 64) ? ~0ull : ((1ull << s) - 1)) & ~(1ull << lane) : 0ull;
+    return build_local_(rows, stride32, Lv, s, lane);
+}
+#define build_local(r, st, lv, s, l) build_local_dbg(r, st, lv, s, l, dbg_flags)
+__device__ __forceinline__ u64 build_local_(const u32 *rows, u32 stride32, u32 Lv, int s, int lane)
 {
     const bool act = lane < s;
     const u32 woff = act ? (Lv >> 5) : 0u;
-    const u32 bit = Lv & 31u;
-    u64 myH = 0;
-    for (int i0 = 0; i0 < s; i0 += FCM_HB) {
+    const u32 bmask = act ? (1u << (Lv & 31u)) : 0u;  // inactive lanes never set a bit
+    u32 hlo = 0u, hhi = 0u;                              // this lane's row, written by v_writelane
+    int i0 = 0;
+    for (; i0 + FCM_HB <= s; i0 += FCM_HB) {             // full batches: FCM_HB row reads in flight
         u32 w[FCM_HB];
 #pragma unroll
         for (int q = 0; q < FCM_HB; ++q) {
-            const int i = min(i0 + q, s - 1);
-            const u32 vi = rdlane(Lv, i);
-            w[q] = rows[(size_t)vi * stride32 + woff];
+            const u32 *row = rows + (size_t)rdlane(Lv, i0 + q) * stride32;  // scalar base + per-lane dword offset
+            w[q] = row[woff];
         }
 #pragma unroll
         for (int q = 0; q < FCM_HB; ++q) {
-            const u64 m = ballot(act && ((w[q] >> bit) & 1u));
-            if (lane == i0 + q) myH = m;
+            const u64 m = ballot((w[q] & bmask) != 0u);
+            hlo = wrlane((u32)m, i0 + q, hlo);
+            hhi = wrlane((u32)(m >> 32), i0 + q, hhi);
         }
     }
-    return act ? myH : 0ull;
+    if (i0 < s) {                                        // last, partial batch: only the rows that exist
+        u32 w[FCM_HB];
+#pragma unroll
+        for (int q = 0; q < FCM_HB; ++q) {
+            w[q] = 0u;
+            if (i0 + q < s) {
+                const u32 *row = rows + (size_t)rdlane(Lv, i0 + q) * stride32;
+                w[q] = row[woff];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < FCM_HB; ++q) {
+            if (i0 + q < s) {
+                const u64 m = ballot((w[q] & bmask) != 0u);
+                hlo = wrlane((u32)m, i0 + q, hlo);
+                hhi = wrlane((u32)(m >> 32), i0 + q, hhi);
+            }
+        }
+    }
+    return (u64)hlo | ((u64)hhi << 32);  // lanes >= s were never written: 0
 }
 
 // Per-lane DFS.  A node has T vertices of K chosen, `cand` = common
@@ -165,7 +220,7 @@ __device__ __forceinline__ void eval_classes(u64 myH, const u64 *Hs, u64 P, u64 
 // u->v must be present in Hs / myH.
 template <int MAXT>
 __device__ __forceinline__ void eval_edge(u64 myH, const u64 *Hs, int iu, int iv, int tmax, int sign, int lane,
-                                          int (&delta)[MAXT + 1])
+                                          int (&delta)[MAXT + 1], int dbg_flags = 0)
 {
     const u64 outU = Hs[iu], outV = Hs[iv];
     const u64 inU = ballot((myH >> iu) & 1ull), inV = ballot((myH >> iv) & 1ull);
@@ -174,6 +229,7 @@ __device__ __forceinline__ void eval_edge(u64 myH, const u64 *Hs, int iu, int iv
     const u64 M = outU & inV & nbm;   // u->w, w->v : between
     const u64 S = outU & outV & nbm;  // u->w, v->w : after v
     u32 dummy = 0;
+    if (g_dbg & 1) { delta[1] += (int)(P ^ M ^ S) & 1; return; }
     eval_classes<MAXT, false>(myH, Hs, P, M, S, tmax, sign, lane, delta, dummy);
 }
 
@@ -185,7 +241,7 @@ __device__ __forceinline__ void eval_edge(u64 myH, const u64 *Hs, int iu, int iv
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
 __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
+                                         u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1], int dbg_flags = 0)
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -198,12 +254,12 @@ __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u3
         res = ab ? 0 : -1;
     } else {
         const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;  // u->v present
-        eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta);
+        eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta, dbg_flags);
         wave_sync();
         if (lane == iu) { myH &= ~(1ull << iv); Hs[lane] = myH; }
         if (lane == iv) { myH |= (1ull << iu); Hs[lane] = myH; }
         wave_sync();
-        eval_edge<MAXT>(myH, Hs, iv, iu, tmax, +1, lane, delta);
+        eval_edge<MAXT>(myH, Hs, iv, iu, tmax, +1, lane, delta, dbg_flags);
         res = ab ? 1 : 2;
     }
     wave_sync();
@@ -215,7 +271,7 @@ __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u3
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
 __device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u32 coin, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
+                                         u32 coin, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1], int dbg_flags = 0)
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -224,7 +280,7 @@ __device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u3
     wave_sync();
     const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
     const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
-    eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta);
+    eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta, dbg_flags);
     wave_sync();
     return (ab & ba) != 0u;
 }
@@ -234,7 +290,7 @@ __device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u3
 // means big->small is the existing direction.
 template <int MAXT>
 __device__ __forceinline__ void add_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u32 fwd, u32 dfrom, u32 dto, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
+                                         u32 fwd, u32 dfrom, u32 dto, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1], int dbg_flags = 0)
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -249,7 +305,7 @@ __device__ __forceinline__ void add_eval(const u32 *rows, u32 stride32, const u3
     if (lane == ib) myH |= (1ull << ia);
     Hs[lane] = myH;
     wave_sync();
-    eval_edge<MAXT>(myH, Hs, ib, ia, tmax, +1, lane, delta);
+    eval_edge<MAXT>(myH, Hs, ib, ia, tmax, +1, lane, delta, dbg_flags);
     wave_sync();
 }
 
@@ -584,7 +640,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     const int k = (int)rdlane(l_e.k, sidx);
                     int res;
                     if (k + 2 <= WAVE) {
-                        res = flip_eval<MAXT>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta);
+                        res = flip_eval<MAXT>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta, p.dbg);
                     } else if (k + 2 <= 64 * maxnw) {
                         const Wide W = wide_carve(smem, maxnw);
                         wide_zero_counts(W, lane);
@@ -659,9 +715,9 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             }
                         } else {
                             // (1) remove delme: subtract simplices through it
-                            okd = del_eval<MAXT>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta);
+                            okd = del_eval<MAXT>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta, p.dbg);
                             // (2) add eb->ea on the graph without delme: add simplices through it
-                            add_eval<MAXT>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta);
+                            add_eval<MAXT>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta, p.dbg);
                         }
                         if (!okd) status |= 2u;  // slot list says reciprocal, bitmap says not
                         c_clr_from = dfrom; c_clr_to = dto;
@@ -689,9 +745,9 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 } else {
 #pragma unroll
                     for (int tq = 1; tq <= MAXT; ++tq) {
-                        if (tq <= tmax) {
-                            const long long sum = wave_sum_i64((long long)delta[tq]);
-                            if (lane == tq + 1) myd = sum;
+                        if (tq <= tmax && !(p.dbg & 4)) {
+                            const int sum = wave_sum_i32(delta[tq]);
+                            if (lane == tq + 1) myd = (long long)sum;
                         }
                     }
                 }
