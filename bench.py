@@ -165,14 +165,13 @@ def main():
     # ---- parity gate on this rank's result (outside the timed region) ----------
     d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k")}
     assert d["sampled"] == (hi - lo) * args.steps * args.proposals, "proposal count mismatch"
-    ablation = os.environ.get("FCM_DBG", "0") != "0"   # profiling-only kernel ablations give wrong counts by design
     def strip(v):  # flag_count never shrinks in length (src/lib.rs:72-74): ignore trailing zeros
         v = list(v)
         while v and v[-1] == 0:
             v.pop()
         return v
 
-    for c in (() if ablation else (0, (hi - lo) // 2, hi - lo - 1)):
+    for c in (0, (hi - lo) // 2, hi - lo - 1):
         assert s.graph(c).flagser_count(local_rank) == strip(s.flag_count(c)), "incremental counts != full recount (chain %d)" % c
         assert bounds.check(s.flag_count(c)), "chain %d left the bounds" % c
 

@@ -54,7 +54,6 @@ __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
         wave_sync();
         if (total <= WAVE) {
             const u32 Lv = lane < (int)total ? Lc[lane] : 0u;
-            const int dbg_flags = 0;
             const u64 myH = build_local(p.rows, p.stride32, Lv, (int)total, lane);
             wave_sync();
             Hs[lane] = myH;

@@ -35,7 +35,6 @@ struct FcmStepParams {
     uint64_t rows_per_chain;   // n * stride32 (u32 words)
     uint32_t n, stride32, U, D, dbl_stride, first_chain, nchains;
     int32_t ncounts;           // tracked count entries NC (<= 16)
-    int32_t dbg;               // ablation flags (profiling only; 0 in production)
     int32_t maxnw;             // mask words the largest local set needs: ceil((k_max+2)/64), 1..4
 };
 

@@ -704,7 +704,6 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     p.nchains = C;
     p.ncounts = nc;
     p.maxnw = s->maxnw_variant;
-    p.dbg = getenv("FCM_DBG") ? atoi(getenv("FCM_DBG")) : 0;
 
     if (s->cfg.sample_distance == 0) s->cfg.sample_distance = fcm_default_sample_distance(fc[1]);  // sample.rs:102
 

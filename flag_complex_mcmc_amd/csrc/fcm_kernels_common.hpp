@@ -99,8 +99,18 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// Single-wave workgroup: orders LDS/global traffic between lanes of the wave.
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// The workgroup is ONE wave.  Vector-memory and LDS instructions of a wave are
+// issued and performed in program order, so data one lane wrote is visible to
+// every lane's later loads without waiting on counters or a barrier (the
+// AMDGPU memory model needs no cache action or wait at wavefront scope).  What
+// is needed is that the compiler keeps the order: a wavefront-scope fence plus a
+// scheduling barrier.  (A __syncthreads() here would add s_waitcnt vmcnt(0) +
+// s_barrier, i.e. a full store round trip, a dozen times per proposal.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ===========================================================================
 // Fast evaluator: local sets of <= 64 vertices, one u64 mask per vertex
@@ -110,17 +120,10 @@ __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 // vertex Lv.  Returns this lane's out-mask over local indices 0..s-1.  One
 // dword per lane per row: bit L[j] of row L[i].  Rows are 128-B multiples, so
 // one row-read is one or few cache lines, shared by the 64 lanes.
-#define FCM_HB 16  // rows in flight per batch
-__device__ int g_dbg_dummy;
-#define g_dbg (dbg_flags)
-__device__ __forceinline__ u64 build_local_(const u32 *rows, u32 stride32, u32 Lv, int s, int lane);
-__device__ __forceinline__ u64 build_local_dbg(const u32 *rows, u32 stride32, u32 Lv, int s, int lane, int dbg_flags)
-{
-    if (g_dbg & 2) return lane < s ? ((u64)Lv * 0x9E3779B97F4A7C15ull) & ((s >= 64) ? ~0ull : ((1ull << s) - 1)) & ~(1ull << lane) : 0ull;
-    return build_local_(rows, stride32, Lv, s, lane);
-}
-#define build_local(r, st, lv, s, l) build_local_dbg(r, st, lv, s, l, dbg_flags)
-__device__ __forceinline__ u64 build_local_(const u32 *rows, u32 stride32, u32 Lv, int s, int lane)
+#ifndef FCM_HB
+#define FCM_HB 24  // rows in flight per batch (16: -2%, 32: -4% on config 3)
+#endif
+__device__ __forceinline__ u64 build_local(const u32 *rows, u32 stride32, u32 Lv, int s, int lane)
 {
     const bool act = lane < s;
     const u32 woff = act ? (Lv >> 5) : 0u;
@@ -220,7 +223,7 @@ __device__ __forceinline__ void eval_classes(u64 myH, const u64 *Hs, u64 P, u64 
 // u->v must be present in Hs / myH.
 template <int MAXT>
 __device__ __forceinline__ void eval_edge(u64 myH, const u64 *Hs, int iu, int iv, int tmax, int sign, int lane,
-                                          int (&delta)[MAXT + 1], int dbg_flags = 0)
+                                          int (&delta)[MAXT + 1])
 {
     const u64 outU = Hs[iu], outV = Hs[iv];
     const u64 inU = ballot((myH >> iu) & 1ull), inV = ballot((myH >> iv) & 1ull);
@@ -229,7 +232,6 @@ __device__ __forceinline__ void eval_edge(u64 myH, const u64 *Hs, int iu, int iv
     const u64 M = outU & inV & nbm;   // u->w, w->v : between
     const u64 S = outU & outV & nbm;  // u->w, v->w : after v
     u32 dummy = 0;
-    if (g_dbg & 1) { delta[1] += (int)(P ^ M ^ S) & 1; return; }
     eval_classes<MAXT, false>(myH, Hs, P, M, S, tmax, sign, lane, delta, dummy);
 }
 
@@ -241,7 +243,7 @@ __device__ __forceinline__ void eval_edge(u64 myH, const u64 *Hs, int iu, int iv
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
 __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1], int dbg_flags = 0)
+                                         u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -254,12 +256,12 @@ __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u3
         res = ab ? 0 : -1;
     } else {
         const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;  // u->v present
-        eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta, dbg_flags);
+        eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta);
         wave_sync();
         if (lane == iu) { myH &= ~(1ull << iv); Hs[lane] = myH; }
         if (lane == iv) { myH |= (1ull << iu); Hs[lane] = myH; }
         wave_sync();
-        eval_edge<MAXT>(myH, Hs, iv, iu, tmax, +1, lane, delta, dbg_flags);
+        eval_edge<MAXT>(myH, Hs, iv, iu, tmax, +1, lane, delta);
         res = ab ? 1 : 2;
     }
     wave_sync();
@@ -271,7 +273,7 @@ __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u3
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
 __device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u32 coin, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1], int dbg_flags = 0)
+                                         u32 coin, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -280,7 +282,7 @@ __device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u3
     wave_sync();
     const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
     const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
-    eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta, dbg_flags);
+    eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta);
     wave_sync();
     return (ab & ba) != 0u;
 }
@@ -290,7 +292,7 @@ __device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u3
 // means big->small is the existing direction.
 template <int MAXT>
 __device__ __forceinline__ void add_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u32 fwd, u32 dfrom, u32 dto, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1], int dbg_flags = 0)
+                                         u32 fwd, u32 dfrom, u32 dto, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -305,7 +307,7 @@ __device__ __forceinline__ void add_eval(const u32 *rows, u32 stride32, const u3
     if (lane == ib) myH |= (1ull << ia);
     Hs[lane] = myH;
     wave_sync();
-    eval_edge<MAXT>(myH, Hs, ib, ia, tmax, +1, lane, delta, dbg_flags);
+    eval_edge<MAXT>(myH, Hs, ib, ia, tmax, +1, lane, delta);
     wave_sync();
 }
 
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     const int k = (int)rdlane(l_e.k, sidx);
                     int res;
                     if (k + 2 <= WAVE) {
-                        res = flip_eval<MAXT>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta, p.dbg);
+                        res = flip_eval<MAXT>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta);
                     } else if (k + 2 <= 64 * maxnw) {
                         const Wide W = wide_carve(smem, maxnw);
                         wide_zero_counts(W, lane);
@@ -715,9 +717,9 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             }
                         } else {
                             // (1) remove delme: subtract simplices through it
-                            okd = del_eval<MAXT>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta, p.dbg);
+                            okd = del_eval<MAXT>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta);
                             // (2) add eb->ea on the graph without delme: add simplices through it
-                            add_eval<MAXT>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta, p.dbg);
+                            add_eval<MAXT>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta);
                         }
                         if (!okd) status |= 2u;  // slot list says reciprocal, bitmap says not
                         c_clr_from = dfrom; c_clr_to = dto;
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 } else {
 #pragma unroll
                     for (int tq = 1; tq <= MAXT; ++tq) {
-                        if (tq <= tmax && !(p.dbg & 4)) {
+                        if (tq <= tmax) {
                             const int sum = wave_sum_i32(delta[tq]);
                             if (lane == tq + 1) myd = (long long)sum;
                         }
