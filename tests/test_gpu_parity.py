@@ -348,3 +348,61 @@ def test_full_size_config3_invariants(fcm):
         assert s.bounds.check(s.flag_count(c))
     assert (counts[:, 0] == n).all() and (counts[:, 1] == len(e)).all()
     assert len({tuple(r) for r in counts.tolist()}) > 200   # chains diverged
+
+
+def test_config4_scale_parity_with_oracle(fcm, oracle):
+    """BASELINE config 4 shape (ER n=4000 p=0.05, rows of 512 B): two chains
+    against their oracle twins, and the initial count against the oracle."""
+    from flag_complex_mcmc_amd import graphs
+    n = 4000
+    e = graphs.random_with_p(n, 0.05, 0)
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e)
+    assert gg.flagser_count() == go.flagser_count()
+    s = fcm.MCMCSampler(gg, b_g, n_chains=2, seed=3, first_chain_id=5)
+    tw = [oracle.Chain(go, b_o, seed=3, chain_id=5 + c) for c in range(2)]
+    for nstep in (70, 330):
+        s.step(nstep)
+        for c in range(2):
+            tw[c].step(nstep)
+            compare_chain(s, c, tw[c], ctx=("config4", c, nstep))
+    assert s.info["row_words"] == 64 and s.info["k_max"] > 62   # wide-path edges exist in this graph
+
+
+def test_config5_scale_invariants(fcm):
+    """BASELINE config 5 shape (n=30000, 1M directed edge draws; rows of 3840 B,
+    115 MB of bitmap per chain): size-independent checks, 4 chains."""
+    from flag_complex_mcmc_amd import graphs
+    n = 30000
+    e = graphs.random_edge_draws(n, 1000000, 0)
+    g = fcm.Graph.from_edges(n, e)
+    s = fcm.initialize_new_sampler(g, n_chains=4, seed=1)
+    s.step(3000)
+    st = s.stats()
+    assert (st["sampled"] == 3000).all() and (st["n_empty"] + st["n_flip"] + st["n_dmove"] == 3000).all()
+    assert (st["n_dmove"] > 0).all()
+    und0 = g.undirected_edges()
+    for c in (0, 3):
+        cur = s.graph(c)
+        fc = s.flag_count(c)
+        while fc[-1] == 0:
+            fc.pop()
+        assert cur.flagser_count() == fc
+        assert cur.nedges() == len(e) and (cur.undirected_edges() == und0).all()
+        assert s.bounds.check(s.flag_count(c))
+    assert not (s.edges(0) == s.edges(3)).all()
+
+
+def test_truncated_mode_tracks_only_the_capped_dimensions(fcm, oracle):
+    """dim_cap (BASELINE configs name caps 5/6/7; the reference has none):
+    dimensions above the cap are not tracked and not bounds-checked; the tracked
+    ones still equal a full recount as long as both runs accept the same moves."""
+    n, e = load_flag_fixture("bug_calc_relax_de.flag")
+    g = fcm.Graph.from_edges(n, e)
+    full = fcm.initialize_new_sampler(g, n_chains=2, seed=2)
+    cap = fcm.initialize_new_sampler(g, n_chains=2, seed=2, dim_cap=4)
+    assert full.info["lossless"] == 1 and full.ncounts == 8
+    assert cap.info["lossless"] == 0 and cap.ncounts == 5
+    cap.step(400)
+    for c in range(2):
+        recount = cap.graph(c).flagser_count()
+        assert recount[:5] == cap.flag_count(c)[:5]
