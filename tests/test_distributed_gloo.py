@@ -46,13 +46,13 @@ WORKER = textwrap.dedent("""
     assert len(vals) == total and mult.sum() == total
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    open(os.path.join(%r, "rank%%d.ok" %% rank), "w").write("ok")   # stdout of the two ranks may interleave
 """)
 
 
 def test_gather_counts_world2_gloo(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
+    script.write_text(WORKER % (ROOT, str(tmp_path)))
     import socket
     with socket.socket() as sk:          # a free port, so reruns never collide with a lingering socket
         sk.bind(("127.0.0.1", 0))
@@ -62,7 +62,7 @@ def test_gather_counts_world2_gloo(tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
 
 
 def test_gather_is_identity_without_process_group():
