@@ -44,7 +44,7 @@ class CSamplerInfo(C.Structure):
     _fields_ = [("n", C.c_uint32), ("row_words", C.c_uint32), ("n_undirected", C.c_uint64),
                 ("n_double", C.c_uint64), ("k_max", C.c_uint32), ("k_mean", C.c_double),
                 ("bytes_per_chain", C.c_uint64), ("bytes_static", C.c_uint64),
-                ("ncounts", C.c_int32), ("lossless", C.c_int32)]
+                ("ncounts", C.c_int32), ("lossless", C.c_int32), ("n_chains", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/fcm.h declares
@@ -87,6 +87,9 @@ SIGNATURES = {
     "fcm_sampler_get_edgebits": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint64, u64p]),
     "fcm_sampler_get_double_slots": (C.c_int, [vp, C.c_uint32, u32p, C.c_uint64, u64p]),
     "fcm_sampler_get_info": (C.c_int, [vp, C.POINTER(CSamplerInfo)]),
+    "fcm_sampler_get_bounds": (C.c_int, [vp, C.POINTER(CBounds)]),
+    "fcm_sampler_save_state": (C.c_int, [vp, C.c_char_p, C.c_uint64]),
+    "fcm_sampler_load_state": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp), u64p]),
 }
 
 _lib = None

@@ -195,7 +195,10 @@ class MCMCSampler:
     """
 
     def __init__(self, graph, bounds, n_chains=1, seed=0, move_weights=MOVE_DISTRIBUTION_SIMPLE,
-                 sample_distance=0, dim_cap=0, device=0, first_chain_id=0):
+                 sample_distance=0, dim_cap=0, device=0, first_chain_id=0, _h=None):
+        if _h is not None:
+            self._adopt(_h, bounds)
+            return
         cfg = CSamplerConfig()
         cfg.n_chains, cfg.first_chain_id, cfg.seed = n_chains, first_chain_id, seed
         for i in range(4):
@@ -203,14 +206,33 @@ class MCMCSampler:
         cfg.sample_distance, cfg.dim_cap, cfg.device = sample_distance, dim_cap, device
         h = C.c_void_p()
         check(lib().fcm_sampler_create(graph._h, C.byref(bounds._c()), C.byref(cfg), C.byref(h)))
+        self._adopt(h, bounds)
+
+    def _adopt(self, h, bounds):
         self._h = h
-        self.n_chains = n_chains
+        if bounds is None:
+            cb = CBounds()
+            check(lib().fcm_sampler_get_bounds(h, C.byref(cb)))
+            bounds = Bounds._from_c(cb)
         self.bounds = bounds
         self.ncounts = int(lib().fcm_sampler_ncounts(h))
         self.sample_distance = int(lib().fcm_sampler_sample_distance(h))
         info = CSamplerInfo()
         check(lib().fcm_sampler_get_info(h, C.byref(info)))
         self.info = {f: getattr(info, f) for f, _ in CSamplerInfo._fields_}
+        self.n_chains = int(self.info["n_chains"])
+
+    def save_state(self, fname, sample_number=0):
+        """io::save_state (src/io.rs:51-56): written to <fname>.tmp, then renamed."""
+        check(lib().fcm_sampler_save_state(self._h, os.fsencode(fname), sample_number))
+
+    @classmethod
+    def load_state(cls, fname, device=0):
+        """io::load_state (src/io.rs:58-62) -> (sample_number, sampler)."""
+        h = C.c_void_p()
+        n = C.c_uint64(0)
+        check(lib().fcm_sampler_load_state(os.fsencode(fname), device, C.byref(h), C.byref(n)))
+        return int(n.value), cls(None, None, _h=h)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -529,6 +529,7 @@ extern "C" uint64_t fcm_default_sample_distance(uint64_t nedges)
 struct fcm_sampler {
     int device = 0;
     fcm_sampler_config cfg{};
+    fcm_bounds bounds{};
     fcm_sampler_info info{};
     FcmStepParams params{};
     int maxt_variant = 6, maxnw_variant = 1;
@@ -583,6 +584,7 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     struct Guard { fcm_sampler *s; ~Guard() { delete s; } } guard{s};
     s->device = cfg->device;
     s->cfg = *cfg;
+    s->bounds = *bounds;
     s->n = g->n;
     s->stride32 = g->stride32;
 
@@ -718,6 +720,8 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     I.bytes_static = etab.size() * sizeof(FcmEdgeEntry) + nb.size() * 4;
     I.ncounts = nc;
     I.lossless = lossless ? 1 : 0;
+    I.n_chains = C;
+    I.reserved = 0;
 
     guard.s = nullptr;
     *out = s;
@@ -902,5 +906,130 @@ extern "C" int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out)
 {
     if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     *out = s->info;
+    return FCM_OK;
+}
+
+
+extern "C" int fcm_sampler_get_bounds(const fcm_sampler *s, fcm_bounds *out)
+{
+    if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    *out = s->bounds;
+    return FCM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Checkpoint / resume (role of src/io.rs:51-62)
+// ---------------------------------------------------------------------------
+static const char FCM_STATE_MAGIC[8] = {'F', 'C', 'M', 'S', 'T', 'A', 'T', '1'};
+
+struct StateHeader {
+    char magic[8];
+    uint64_t sample_number;
+    uint32_t n, n_chains;
+    uint64_t U, D;
+    int32_t ncounts, reserved;
+    fcm_sampler_config cfg;
+    fcm_bounds bounds;
+};
+
+template <class T> static bool wr(FILE *f, const T *p, size_t cnt) { return cnt == 0 || fwrite(p, sizeof(T), cnt, f) == cnt; }
+template <class T> static bool rd(FILE *f, T *p, size_t cnt) { return cnt == 0 || fread(p, sizeof(T), cnt, f) == cnt; }
+
+extern "C" int fcm_sampler_save_state(fcm_sampler *s, const char *path, uint64_t sample_number)
+{
+    if (!s || !path) return fail(FCM_ERR_INVALID, "NULL argument");
+    std::vector<uint64_t> hs;
+    int rc = fetch_stats(s, hs);   // syncs; refuses to save a chain whose device-side checks failed
+    if (rc) return rc;
+    const uint32_t C = s->params.nchains;
+    const uint64_t U = s->ue.size() / 2, D = s->params.D;
+    const uint64_t rec = (2 * U + 7) / 8;
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(FCM_ERR_IO, "cannot write %s", tmp.c_str());
+    StateHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, FCM_STATE_MAGIC, 8);
+    h.sample_number = sample_number;
+    h.n = s->n; h.n_chains = C; h.U = U; h.D = D; h.ncounts = s->params.ncounts;
+    h.cfg = s->cfg; h.bounds = s->bounds;
+    bool ok = wr(f, &h, 1) && wr(f, s->ue.data(), s->ue.size());
+    std::vector<uint64_t> hc((size_t)C * FCM_MAX_COUNTS);
+    if (hipMemcpy(hc.data(), s->d_counts.p, hc.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+    ok = ok && wr(f, hc.data(), hc.size()) && wr(f, hs.data(), hs.size());
+    std::vector<uint8_t> bits((size_t)rec);
+    std::vector<uint32_t> dbl((size_t)D);
+    for (uint32_t c = 0; ok && c < C; ++c) {
+        uint64_t nb = 0;
+        if (fcm_sampler_get_edgebits(s, c, bits.data(), rec, &nb) != FCM_OK) { fclose(f); remove(tmp.c_str()); return FCM_ERR_HIP; }
+        if (fcm_sampler_get_double_slots(s, c, dbl.data(), D, nullptr) != FCM_OK) { fclose(f); remove(tmp.c_str()); return FCM_ERR_HIP; }
+        ok = wr(f, bits.data(), bits.size()) && wr(f, dbl.data(), dbl.size());
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { remove(tmp.c_str()); return fail(FCM_ERR_IO, "write to %s failed", tmp.c_str()); }
+    if (rename(tmp.c_str(), path) != 0) return fail(FCM_ERR_IO, "moving temp state file to %s failed", path);
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_load_state(const char *path, int device, fcm_sampler **out, uint64_t *sample_number)
+{
+    if (!path || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(FCM_ERR_IO, "unable to load state %s", path);
+    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{f};
+    StateHeader h;
+    if (!rd(f, &h, 1) || memcmp(h.magic, FCM_STATE_MAGIC, 8) != 0) return fail(FCM_ERR_IO, "%s is not a libfcm state file", path);
+    if (h.n_chains == 0 || h.ncounts < 2 || h.ncounts > FCM_MAX_COUNTS) return fail(FCM_ERR_IO, "%s: corrupt header", path);
+    const uint64_t U = h.U, D = h.D, rec = (2 * U + 7) / 8;
+    std::vector<uint32_t> ue((size_t)U * 2);
+    std::vector<uint64_t> hc((size_t)h.n_chains * FCM_MAX_COUNTS), hs((size_t)h.n_chains * FCM_NSTATS);
+    if (!rd(f, ue.data(), ue.size()) || !rd(f, hc.data(), hc.size()) || !rd(f, hs.data(), hs.size()))
+        return fail(FCM_ERR_IO, "%s: truncated", path);
+    for (uint64_t e = 0; e < U; ++e)
+        if (ue[2 * e] >= h.n || ue[2 * e + 1] >= ue[2 * e]) return fail(FCM_ERR_IO, "%s: corrupt pair list", path);
+
+    // a graph with the right pr(G) (orientation of chain 0) to rebuild the static tables from
+    std::vector<uint8_t> bits((size_t)rec);
+    std::vector<uint32_t> dbl((size_t)D);
+    const long chain_pos = ftell(f);
+    if (!rd(f, bits.data(), bits.size())) return fail(FCM_ERR_IO, "%s: truncated", path);
+    fcm_graph *g = nullptr;
+    int rc = fcm_graph_new_disconnected(h.n, &g);
+    if (rc) return rc;
+    struct GG { fcm_graph *g; ~GG() { delete g; } } gg{g};
+    auto apply_bits = [&](fcm_graph &gr) {
+        std::fill(gr.rows.begin(), gr.rows.end(), 0u);
+        gr.m = 0;
+        for (uint64_t e = 0; e < U; ++e) {
+            if ((bits[(2 * e) >> 3] >> ((2 * e) & 7)) & 1) gr.set(ue[2 * e], ue[2 * e + 1], true);
+            if ((bits[(2 * e + 1) >> 3] >> ((2 * e + 1) & 7)) & 1) gr.set(ue[2 * e + 1], ue[2 * e], true);
+        }
+    };
+    apply_bits(*g);
+    fcm_sampler_config cfg = h.cfg;
+    cfg.device = device;
+    fcm_sampler *s = nullptr;
+    if ((rc = fcm_sampler_create(g, &h.bounds, &cfg, &s))) return rc;
+    struct SG { fcm_sampler *s; ~SG() { if (s) fcm_sampler_destroy(s); } } sg{s};
+    if (s->params.U != U || s->params.ncounts != h.ncounts || s->params.nchains != h.n_chains)
+        return fail(FCM_ERR_IO, "%s: state does not match the tables rebuilt from it", path);
+    // per-chain state
+    if (fseek(f, chain_pos, SEEK_SET) != 0) return fail(FCM_ERR_IO, "%s: seek failed", path);
+    for (uint32_t c = 0; c < h.n_chains; ++c) {
+        if (!rd(f, bits.data(), bits.size()) || !rd(f, dbl.data(), dbl.size())) return fail(FCM_ERR_IO, "%s: truncated", path);
+        apply_bits(*g);
+        HIP_TRY(hipMemcpy(s->d_rows.as<uint32_t>() + (size_t)c * s->params.rows_per_chain, g->rows.data(),
+                          (size_t)s->params.rows_per_chain * sizeof(uint32_t), hipMemcpyHostToDevice));
+        uint64_t nd = 0;
+        for (uint64_t e = 0; e < U; ++e) nd += g->has(ue[2 * e], ue[2 * e + 1]) && g->has(ue[2 * e + 1], ue[2 * e]);
+        if (nd != D) return fail(FCM_ERR_IO, "%s: chain %u has %llu reciprocal pairs, header says %llu", path, c,
+                                 (unsigned long long)nd, (unsigned long long)D);
+        if (D) HIP_TRY(hipMemcpy(s->d_dbl.as<uint32_t>() + (size_t)c * s->params.dbl_stride, dbl.data(), (size_t)D * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(s->d_counts.p, hc.data(), hc.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_stats.p, hs.data(), hs.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (sample_number) *sample_number = h.sample_number;
+    sg.s = nullptr;
+    *out = s;
     return FCM_OK;
 }

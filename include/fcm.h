@@ -199,6 +199,19 @@ int fcm_sampler_get_edgebits(fcm_sampler *s, uint32_t chain, uint8_t *out, uint6
 /* The chain's reciprocal-pair slot list (DESIGN.md draw spec), for parity tests. */
 int fcm_sampler_get_double_slots(fcm_sampler *s, uint32_t chain, uint32_t *out, uint64_t cap, uint64_t *n);
 
+/* ------------------------------------------------------------------------ */
+/* Checkpoint / resume: the role of io::save_state / io::load_state           */
+/* (src/io.rs:51-62; called at src/bin/sample.rs:114-115,129-132,146).  Own    */
+/* format (the reference's is bincode of serde-derived types that live in the */
+/* absent crate): header, bounds, config, the adjacent pairs,   */
+/* and per chain the 2-bit orientation record (= one edgebits record), the    */
+/* reciprocal-pair slot list, counts and counters (incl. the Philox position  */
+/* = sampled).  Written to <path>.tmp then renamed, like the reference.       */
+/* `sample_number` is the caller's loop index, stored and returned verbatim.  */
+/* ------------------------------------------------------------------------ */
+int fcm_sampler_save_state(fcm_sampler *s, const char *path, uint64_t sample_number);
+int fcm_sampler_load_state(const char *path, int device, fcm_sampler **out, uint64_t *sample_number);
+
 /* Static facts about the sampler (for bench accounting). */
 typedef struct {
     uint32_t n;                /* vertices */
@@ -211,8 +224,12 @@ typedef struct {
     uint64_t bytes_static;     /* HBM bytes of shared read-only tables */
     int32_t ncounts;
     int32_t lossless;          /* 1 if every reachable dimension is tracked */
+    uint32_t n_chains;
+    uint32_t reserved;
 } fcm_sampler_info;
 int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out);
+/* The Bounds the sampler checks against (MCMCSampler::bounds, src/lib.rs:170). */
+int fcm_sampler_get_bounds(const fcm_sampler *s, fcm_bounds *out);
 
 #ifdef __cplusplus
 }

@@ -406,3 +406,43 @@ def test_truncated_mode_tracks_only_the_capped_dimensions(fcm, oracle):
     for c in range(2):
         recount = cap.graph(c).flagser_count()
         assert recount[:5] == cap.flag_count(c)[:5]
+
+
+# ------------------------------------------- checkpoint / resume (src/io.rs:51-62)
+def test_save_state_load_state_resumes_exactly(fcm, oracle, tmp_path):
+    from flag_complex_mcmc_amd import graphs
+    e = graphs.random_with_p(150, 0.15, seed=2)
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, 150, e)
+    a = fcm.MCMCSampler(gg, b_g, n_chains=5, seed=7, first_chain_id=11, sample_distance=250)
+    a.next()
+    path = tmp_path / "sampler-lab-007.state"
+    a.save_state(str(path), sample_number=42)
+    assert path.exists() and not (tmp_path / "sampler-lab-007.state.tmp").exists()   # tmp-then-rename (io.rs:52-54)
+    n, b = fcm.MCMCSampler.load_state(str(path))
+    assert n == 42 and b.n_chains == 5 and b.sample_distance == 250
+    assert (b.bounds.flag_count_min, b.bounds.flag_count_max) == (b_g.flag_count_min, b_g.flag_count_max)
+    assert (a.flag_counts() == b.flag_counts()).all()
+    a.next()
+    b.next()
+    straight = fcm.MCMCSampler(gg, b_g, n_chains=5, seed=7, first_chain_id=11, sample_distance=250)
+    straight.step(500)
+    for s in (a, b):
+        assert (s.flag_counts() == straight.flag_counts()).all()
+        for k, v in straight.stats().items():
+            assert (s.stats()[k] == v).all(), k
+        for c in range(5):
+            assert (s.edges(c) == straight.edges(c)).all()
+            assert (s.double_slots(c) == straight.double_slots(c)).all()
+    tw = oracle.Chain(go, b_o, seed=7, chain_id=13)
+    tw.step(500)
+    compare_chain(b, 2, tw)
+
+
+def test_load_state_rejects_garbage(fcm, tmp_path):
+    p = tmp_path / "x.state"
+    p.write_bytes(b"not a state file at all" * 10)
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MCMCSampler.load_state(str(p))
+    assert ei.value.code == 5
+    with pytest.raises(fcm.FcmError):
+        fcm.MCMCSampler.load_state(str(tmp_path / "missing.state"))
