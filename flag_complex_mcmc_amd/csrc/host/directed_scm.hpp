@@ -1,0 +1,252 @@
+// directed_scm.hpp — C++ host-side mirror of the reference crate's interface
+// for the hot path (reference `directed-scm`: src/lib.rs, src/io.rs), over the
+// C ABI of libfcm.so.  Header-only; names and argument meaning follow the
+// reference so that code written against it reads the same:
+//
+//   reference (Rust)                         here
+//   flag_complex::Graph                      fcm::Graph
+//   Bounds{flag_count_min, flag_count_max}   fcm::Bounds           (src/lib.rs:113-161)
+//   MCMCSampler<R>                           fcm::MCMCSampler      (src/lib.rs:163-198), a batch of chains
+//   io::read_flag_file / save_flag_file      fcm::io::...          (src/io.rs:18-48)
+//   io::save_state / load_state              MCMCSampler::save_state / load_state (src/io.rs:51-62)
+//   io::BitOutput                            fcm::io::BitOutput    (src/io.rs:128-212)
+//
+// Rust panics (unwrap/expect/assert!) become fcm::Error exceptions.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <sys/stat.h>
+#include <utility>
+#include <vector>
+
+#include "../../../include/fcm.h"
+
+namespace fcm {
+
+using Node = fcm_node;                 // u32
+using Edge = std::pair<Node, Node>;    // [from, to]
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc)
+{
+    if (rc != FCM_OK) throw Error(rc, fcm_last_error());
+}
+
+class Graph {
+public:
+    explicit Graph(fcm_graph *h) : h_(h) {}
+    Graph(const Graph &) = delete;
+    Graph &operator=(const Graph &) = delete;
+    Graph(Graph &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    ~Graph() { fcm_graph_destroy(h_); }
+
+    static Graph new_disconnected(size_t nnodes) { fcm_graph *h; check(fcm_graph_new_disconnected((uint32_t)nnodes, &h)); return Graph(h); }
+    size_t nnodes() const { return fcm_graph_nnodes(h_); }
+    bool has_edge(Node a, Node b) const { return fcm_graph_has_edge(h_, a, b) != 0; }
+    void set_edge(Node a, Node b, bool present) { check(fcm_graph_set_edge(h_, a, b, present)); }
+    void add_edge(Node a, Node b) { check(fcm_graph_add_edge(h_, a, b)); }
+    void remove_edge(Node a, Node b) { check(fcm_graph_remove_edge(h_, a, b)); }
+    std::vector<Edge> edges() const { return pairs(&fcm_graph_edges); }
+    std::vector<Edge> undirected_edges() const { return pairs(&fcm_graph_undirected_edges); }
+    /// directed flag complex cell counts, on the GPU
+    std::vector<size_t> flagser_count(int device = 0) const
+    {
+        uint64_t c[FCM_MAX_COUNTS];
+        int len = 0;
+        check(fcm_graph_flagser_count(h_, device, c, FCM_MAX_COUNTS, &len));
+        return std::vector<size_t>(c, c + len);
+    }
+    fcm_graph *raw() const { return h_; }
+
+private:
+    std::vector<Edge> pairs(int (*fn)(const fcm_graph *, fcm_node *, uint64_t, uint64_t *)) const
+    {
+        uint64_t m = 0;
+        check(fn(h_, nullptr, 0, &m));
+        std::vector<fcm_node> flat(2 * m + 2);
+        check(fn(h_, flat.data(), m, &m));
+        std::vector<Edge> out(m);
+        for (uint64_t i = 0; i < m; ++i) out[i] = {flat[2 * i], flat[2 * i + 1]};
+        return out;
+    }
+    fcm_graph *h_;
+};
+
+struct Bounds {
+    std::vector<size_t> flag_count_min, flag_count_max;
+
+    fcm_bounds c() const
+    {
+        fcm_bounds b{};
+        if (flag_count_min.size() > FCM_MAX_COUNTS + 1 || flag_count_max.size() > FCM_MAX_COUNTS + 1)
+            throw Error(FCM_ERR_UNSUPPORTED, "bounds longer than FCM_MAX_COUNTS+1");
+        for (size_t i = 0; i < flag_count_min.size(); ++i) b.flag_count_min[i] = flag_count_min[i];
+        for (size_t i = 0; i < flag_count_max.size(); ++i) b.flag_count_max[i] = flag_count_max[i];
+        b.min_len = (int32_t)flag_count_min.size();
+        b.max_len = (int32_t)flag_count_max.size();
+        return b;
+    }
+    static Bounds from_c(const fcm_bounds &b)
+    {
+        Bounds r;
+        r.flag_count_min.assign(b.flag_count_min, b.flag_count_min + b.min_len);
+        r.flag_count_max.assign(b.flag_count_max, b.flag_count_max + b.max_len);
+        return r;
+    }
+    /// src/bin/sample.rs:89-95
+    static Bounds target(const std::vector<size_t> &flag_count, double target_relaxation)
+    {
+        std::vector<uint64_t> fc(flag_count.begin(), flag_count.end());
+        fcm_bounds b;
+        check(fcm_target_bounds(fc.data(), (int)fc.size(), target_relaxation, &b));
+        return from_c(b);
+    }
+    /// Bounds::calculate (src/lib.rs:119-156)
+    static Bounds calculate(const Graph &initial_graph, const std::vector<size_t> &initial_flag_count,
+                            const Bounds &target_bounds, int device = 0)
+    {
+        std::vector<uint64_t> fc(initial_flag_count.begin(), initial_flag_count.end());
+        const fcm_bounds t = target_bounds.c();
+        fcm_bounds out;
+        check(fcm_bounds_calculate(initial_graph.raw(), fc.data(), (int)fc.size(), &t, device, &out, nullptr, nullptr));
+        return from_c(out);
+    }
+    /// Bounds::check (src/lib.rs:157-160)
+    bool check_counts(const std::vector<size_t> &flag_count) const
+    {
+        std::vector<uint64_t> fc(flag_count.begin(), flag_count.end());
+        const fcm_bounds b = c();
+        return fcm_bounds_check(&b, fc.data(), (int)fc.size()) != 0;
+    }
+};
+
+/// A batch of independent MCMCSampler chains on one GPU.
+class MCMCSampler {
+public:
+    MCMCSampler(const Graph &g, const Bounds &bounds, uint32_t n_chains, uint64_t seed, const double (&move_weights)[4],
+                size_t sample_distance = 0, int device = 0, int dim_cap = 0, uint32_t first_chain_id = 0)
+    {
+        fcm_sampler_config cfg{};
+        cfg.n_chains = n_chains;
+        cfg.first_chain_id = first_chain_id;
+        cfg.seed = seed;
+        for (int i = 0; i < 4; ++i) cfg.move_weights[i] = move_weights[i];
+        cfg.sample_distance = sample_distance;
+        cfg.dim_cap = dim_cap;
+        cfg.device = device;
+        const fcm_bounds b = bounds.c();
+        check(fcm_sampler_create(g.raw(), &b, &cfg, &h_));
+        refresh();
+    }
+    explicit MCMCSampler(fcm_sampler *h) : h_(h) { refresh(); }
+    MCMCSampler(const MCMCSampler &) = delete;
+    MCMCSampler(MCMCSampler &&o) noexcept : h_(o.h_), info_(o.info_) { o.h_ = nullptr; }
+    ~MCMCSampler() { fcm_sampler_destroy(h_); }
+
+    /// MCMCSampler::next (src/lib.rs:181-194): sample_distance proposals on every chain
+    void next() { check(fcm_sampler_next(h_)); }
+    void step(uint64_t n_proposals) { check(fcm_sampler_step(h_, n_proposals)); check(fcm_sampler_sync(h_)); }
+
+    uint32_t n_chains() const { return info_.n_chains; }
+    size_t sample_distance() const { return fcm_sampler_sample_distance(h_); }
+    Bounds bounds() const { fcm_bounds b; check(fcm_sampler_get_bounds(h_, &b)); return Bounds::from_c(b); }
+
+    /// state.flag_count of every chain, as the reference would print it
+    std::vector<std::vector<size_t>> flag_counts()
+    {
+        const int nc = fcm_sampler_ncounts(h_);
+        std::vector<uint64_t> flat((size_t)n_chains() * nc);
+        std::vector<int32_t> len(n_chains());
+        check(fcm_sampler_get_counts(h_, flat.data(), len.data()));
+        std::vector<std::vector<size_t>> out(n_chains());
+        for (uint32_t c = 0; c < n_chains(); ++c) out[c].assign(flat.begin() + (size_t)c * nc, flat.begin() + (size_t)c * nc + len[c]);
+        return out;
+    }
+    struct Metrics { uint64_t sampled, accepted; double acceptance_ratio() const { return (double)accepted / (double)sampled; } };
+    std::vector<Metrics> metrics()
+    {
+        std::vector<uint64_t> st((size_t)n_chains() * FCM_NSTATS);
+        check(fcm_sampler_get_stats(h_, st.data()));
+        std::vector<Metrics> out(n_chains());
+        for (uint32_t c = 0; c < n_chains(); ++c) out[c] = {st[(size_t)c * FCM_NSTATS + FCM_STAT_SAMPLED], st[(size_t)c * FCM_NSTATS + FCM_STAT_ACCEPTED]};
+        return out;
+    }
+    std::vector<uint8_t> edgebits(uint32_t chain)
+    {
+        uint64_t n = 0;
+        check(fcm_sampler_get_edgebits(h_, chain, nullptr, 0, &n));
+        std::vector<uint8_t> out(n);
+        check(fcm_sampler_get_edgebits(h_, chain, out.data(), n, &n));
+        return out;
+    }
+    Graph graph(uint32_t chain)
+    {
+        uint64_t m = 0;
+        check(fcm_sampler_get_edges(h_, chain, nullptr, 0, &m));
+        std::vector<fcm_node> flat(2 * m + 2);
+        check(fcm_sampler_get_edges(h_, chain, flat.data(), m, &m));
+        fcm_graph *g;
+        check(fcm_graph_from_edges(info_.n, m, flat.data(), &g));
+        return Graph(g);
+    }
+    /// io::save_state / io::load_state (src/io.rs:51-62)
+    void save_state(const std::string &fname, size_t sample_number) { check(fcm_sampler_save_state(h_, fname.c_str(), sample_number)); }
+    static std::pair<size_t, MCMCSampler> load_state(const std::string &fname, int device = 0)
+    {
+        fcm_sampler *h;
+        uint64_t n = 0;
+        check(fcm_sampler_load_state(fname.c_str(), device, &h, &n));
+        return {(size_t)n, MCMCSampler(h)};
+    }
+    const fcm_sampler_info &info() const { return info_; }
+
+private:
+    void refresh() { check(fcm_sampler_get_info(h_, &info_)); }
+    fcm_sampler *h_ = nullptr;
+    fcm_sampler_info info_{};
+};
+
+namespace io {
+inline Graph read_flag_file(const std::string &fname) { fcm_graph *g; check(fcm_read_flag_file(fname.c_str(), &g)); return Graph(g); }
+inline void save_flag_file(const std::string &fname, const Graph &g) { check(fcm_save_flag_file(fname.c_str(), g.raw())); }
+
+/// io::BitOutput (src/io.rs:128-212): <dir>/graph.flag and <dir>/N.edgebits
+class BitOutput {
+public:
+    BitOutput(const Graph &graph, const std::string &dir) : dir_(dir)
+    {
+        mkdir(dir.c_str(), 0777);  // AlreadyExists is fine (io.rs:143-146)
+        save_flag_file(dir + "/graph.flag", graph);
+        const size_t nslots = 2 * graph.undirected_edges().size();
+        if (nslots / 8 == 0) throw Error(FCM_ERR_PANIC, "fewer than 8 edge slots: reference BitOutput::new divides by zero (src/io.rs:161)");
+        chunk_size_ = std::max<size_t>(2000000000 / (nslots / 8), 1);
+    }
+    ~BitOutput() { if (f_) fclose(f_); }
+    void save(MCMCSampler &s, uint32_t chain)
+    {
+        if (index_in_file_ == 0) {
+            f_ = fopen((dir_ + "/" + std::to_string(index_in_dir_) + ".edgebits").c_str(), "wb");
+            if (!f_) throw Error(FCM_ERR_IO, "cannot create edgebits file in " + dir_);
+        }
+        const std::vector<uint8_t> rec = s.edgebits(chain);
+        if (fwrite(rec.data(), 1, rec.size(), f_) != rec.size()) throw Error(FCM_ERR_IO, "edgebits write failed");
+        if (++index_in_file_ == chunk_size_) { fclose(f_); f_ = nullptr; index_in_file_ = 0; ++index_in_dir_; }
+    }
+    void flush() { if (f_) fflush(f_); }
+
+private:
+    std::string dir_;
+    size_t chunk_size_ = 1, index_in_file_ = 0, index_in_dir_ = 0;
+    FILE *f_ = nullptr;
+};
+}  // namespace io
+
+static const double MOVE_DISTRIBUTION_SIMPLE[4] = {0.5, 0.5, 0.0, 0.0};  // src/bin/sample.rs:16
+static const double MOVE_DISTRIBUTION[4] = {0.1, 0.1, 0.6, 0.2};         // src/bin/sample.rs:17 (clique moves not built)
+
+}  // namespace fcm

@@ -446,3 +446,43 @@ def test_load_state_rejects_garbage(fcm, tmp_path):
     assert ei.value.code == 5
     with pytest.raises(fcm.FcmError):
         fcm.MCMCSampler.load_state(str(tmp_path / "missing.state"))
+
+
+# ------------------------------------------- the `sample` CLI (src/bin/sample.rs)
+def test_sample_cli_matches_library_and_resumes(fcm, golden_dir, tmp_path):
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(fcm.LIB_PATH), "sample")
+    assert os.path.exists(exe), "build it with make -C flag_complex_mcmc_amd/csrc"
+    flag = os.path.join(golden_dir, "bug_calc_relax_de.flag")
+    sdir, stdir = tmp_path / "samples", tmp_path / "state"
+    base = [exe, "-i", flag, "-l", "lab", "-s", "4", "--simple", "--chains", "3", "--sample-distance", "150",
+            "--samples-store-dir", str(sdir), "--state-store-dir", str(stdir), "--state-save-interval", "2"]
+    r = subprocess.run(base + ["-n", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "The sampling distance was set to 150." in r.stdout and r.stdout.count("flag count: [") == 3
+    state = stdir / "sampler-lab-004.state"
+    assert state.exists()
+    # the same three samples through the library
+    s = fcm.initialize_new_sampler(flag, target_relaxation=0.01, seed=4, n_chains=3, sample_distance=150)
+    recs = {c: b"" for c in range(3)}
+    for _ in range(3):
+        s.next()
+        for c in range(3):
+            recs[c] += s.edgebits(c).tobytes()
+    for c in range(3):
+        d = sdir / "lab-004" / ("chain%05d" % c)
+        assert (d / "graph.flag").exists()
+        assert (d / "0.edgebits").read_bytes() == recs[c]
+    assert "flag count: %s" % s.flag_count(0) in r.stdout
+    # resume (-c) for two more samples == five samples straight
+    r2 = subprocess.run([exe, "-c", str(state), "-l", "lab", "-s", "4", "-n", "2", "--samples-store-dir", str(tmp_path / "s2"),
+                         "--state-store-dir", str(stdir)], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    s.next(); s.next()
+    assert "flag count: %s" % s.flag_count(0) in r2.stdout
+    n, resumed = fcm.MCMCSampler.load_state(str(state))
+    assert n == 5 and (resumed.flag_counts() == s.flag_counts()).all()
+    # without --simple the CLI refuses (clique moves are not built)
+    r3 = subprocess.run([exe, "-i", flag, "-l", "x", "--samples-store-dir", str(tmp_path / "s3"), "--state-store-dir", str(stdir)],
+                        capture_output=True, text=True, timeout=300)
+    assert r3.returncode != 0 and "simple" in r3.stderr
