@@ -61,8 +61,9 @@ __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
             int delta[FCM_COUNT_MAXT + 1];
 #pragma unroll
             for (int q = 0; q <= FCM_COUNT_MAXT; ++q) delta[q] = 0;
-            const u64 S = total >= 64 ? ~0ull : ((1ull << total) - 1ull);
-            eval_classes<FCM_COUNT_MAXT, true>(myH, Hs, 0ull, 0ull, S, FCM_COUNT_MAXT, +1, lane, delta, overflow);
+            // every vertex of C comes after v: one class, the raw masks are the clique graph
+            if (lane < (int)total) delta[1] += 1;
+            if (myH) visit<1, FCM_COUNT_MAXT, true>(myH, Hs, FCM_COUNT_MAXT, +1, delta, overflow);
 #pragma unroll
             for (int q = 1; q <= FCM_COUNT_MAXT; ++q) acc[q] += (u64)(u32)delta[q];
         } else {

@@ -620,7 +620,9 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     }
     if (kmax + 2 > FCM_MAX_LOCAL)
         return fail(FCM_ERR_UNSUPPORTED, "an edge has %u common neighbours; this build supports at most %d", kmax, FCM_MAX_LOCAL - 2);
-    s->maxnw_variant = kmax + 2 <= 64 ? 1 : (kmax + 2 <= 128 ? 2 : 4);
+    // at least two mask words of LDS: the one-word path falls back to the wide one when the
+    // per-class copies of multi-class vertices do not fit in 64 nodes
+    s->maxnw_variant = kmax + 2 <= 128 ? 2 : 4;
     const uint64_t D = dbl0.size();
 
     // --- initial counts and the reachable dimension range ------------------

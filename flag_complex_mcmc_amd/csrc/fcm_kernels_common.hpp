@@ -166,30 +166,60 @@ __device__ __forceinline__ u64 build_local(const u32 *rows, u32 stride32, u32 Lv
     return (u64)hlo | ((u64)hhi << 32);  // lanes >= s were never written: 0
 }
 
-// Per-lane DFS.  A node has T vertices of K chosen, `cand` = common
-// out-neighbours still allowed (non-empty, already restricted to classes
-// >= ph).  Children with class ph2 >= ph each add one simplex with T+1
-// K-vertices.  delta[t] accumulates sign * (#simplices with t K-vertices).
+// ---------------------------------------------------------------------------
+// Counting the simplices through an edge u->v on the local set.
+//
+// A vertex w of K = N(u) cap N(v) can sit before u (class P: w->u, w->v),
+// between (M: u->w, w->v) or after v (S: u->w, v->w); with reciprocal pairs it
+// can have several classes.  A simplex through u->v is an ordered clique of K
+// whose class sequence is P*M*S*.  Instead of carrying the phase through the
+// walk, the phase order is folded into the graph ("node splitting"): one node
+// per (vertex, class), an arc (w,c)->(x,c') iff w->x and c' >= c.  Ordered
+// cliques of that graph are exactly the simplices wanted, so the walk is a
+// plain clique enumeration: cand & Hp[x], popcount at the leaves.
+//
+// Node indices: a vertex's first class lives at the vertex's own local index;
+// its further classes ("extras", a handful per evaluation) take the two
+// indices of u and v (never nodes themselves) and then the free indices from
+// s upwards.  If they do not fit in 64 the caller falls back to the wide path.
+// ---------------------------------------------------------------------------
+#define FCM_NEEDS_WIDE (-2)
+
+struct Cls { u64 P, M, S; };
+
+// classes relative to u->v (local indices iu, iv); the edge must be present
+__device__ __forceinline__ Cls classify(u64 myH, const u64 *Hs, int iu, int iv)
+{
+    const u64 outU = Hs[iu], outV = Hs[iv];
+    const u64 inU = ballot((myH >> iu) & 1ull), inV = ballot((myH >> iv) & 1ull);
+    const u64 nbm = ~((1ull << iu) | (1ull << iv));
+    Cls c;
+    c.P = inU & inV & nbm;    // w->u, w->v : before u
+    c.M = outU & inV & nbm;   // u->w, w->v : between
+    c.S = outU & outV & nbm;  // u->w, v->w : after v
+    return c;
+}
+__device__ __forceinline__ bool extras_fit(const Cls &c, int s)
+{
+    const int ne = __popcll(c.P & c.M) + __popcll(c.S & (c.P | c.M));
+    return ne <= 2 + (WAVE - s);
+}
+
+// Plain clique walk.  A node has T vertices chosen; `cand` = its children
+// (non-empty).  delta[t] accumulates sign * (#cliques with t vertices).
 template <int T, int MAXT, bool DETECT>
-__device__ __forceinline__ void dfs_level(u64 cand, int ph, const u64 *Hs, u64 P, u64 M, u64 S,
-                                          int tmax, int sign, int (&delta)[MAXT + 1], u32 &overflow)
+__device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sign, int (&delta)[MAXT + 1], u32 &overflow)
 {
     if constexpr (T < MAXT) {
         if (T + 1 <= tmax) {
-            const bool deeper = DETECT || (T + 2 <= tmax);
-#pragma nounroll
-            for (int ph2 = ph; ph2 < 3; ++ph2) {
-                const u64 cm = ph2 == 0 ? P : (ph2 == 1 ? M : S);
-                u64 c = cand & cm;
-                delta[T + 1] += sign * __popcll(c);
-                if (deeper) {
-                    const u64 ge = ph2 == 0 ? (P | M | S) : (ph2 == 1 ? (M | S) : S);
-                    while (c) {
-                        const int x = __ffsll((long long)c) - 1;
-                        c &= c - 1;
-                        const u64 nc = cand & Hs[x] & ge;
-                        if (nc) dfs_level<T + 1, MAXT, DETECT>(nc, ph2, Hs, P, M, S, tmax, sign, delta, overflow);
-                    }
+            delta[T + 1] += sign * __popcll(cand);
+            if (DETECT || T + 2 <= tmax) {
+                u64 c = cand;
+                while (c) {
+                    const int x = __ffsll((long long)c) - 1;
+                    c &= c - 1;
+                    const u64 nc = cand & Hp[x];
+                    if (nc) visit<T + 1, MAXT, DETECT>(nc, Hp, tmax, sign, delta, overflow);
                 }
             }
         } else if (DETECT) {
@@ -200,50 +230,67 @@ __device__ __forceinline__ void dfs_level(u64 cand, int ph, const u64 *Hs, u64 P
     }
 }
 
-// Count simplices through the classified local set.  Lane = first K-vertex.
-template <int MAXT, bool DETECT>
-__device__ __forceinline__ void eval_classes(u64 myH, const u64 *Hs, u64 P, u64 M, u64 S, int tmax, int sign,
-                                             int lane, int (&delta)[MAXT + 1], u32 &overflow)
-{
-    const u32 cb = (u32)((P >> lane) & 1ull) | ((u32)((M >> lane) & 1ull) << 1) | ((u32)((S >> lane) & 1ull) << 2);
-    if (tmax >= 1) delta[1] += sign * __popc(cb);
-    if (cb && tmax >= 2) {
-#pragma nounroll
-        for (int ph = 0; ph < 3; ++ph) {
-            if ((cb >> ph) & 1u) {
-                const u64 ge = ph == 0 ? (P | M | S) : (ph == 1 ? (M | S) : S);
-                const u64 nc = myH & ge;
-                if (nc) dfs_level<1, MAXT, DETECT>(nc, ph, Hs, P, M, S, tmax, sign, delta, overflow);
-            }
-        }
-    }
-}
-
-// E(G, u->v) on the local set: iu, iv = local indices of u and v; the edge
-// u->v must be present in Hs / myH.
+// E(G, u->v): builds the split graph for classes `c` into Hp and counts.
+// myH / Hs hold the raw local adjacency; local indices k, k+1 are the edge's
+// endpoints.  Requires extras_fit(c, k+2).
 template <int MAXT>
-__device__ __forceinline__ void eval_edge(u64 myH, const u64 *Hs, int iu, int iv, int tmax, int sign, int lane,
-                                          int (&delta)[MAXT + 1])
+__device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k, int tmax, int sign, int lane,
+                                           int (&delta)[MAXT + 1])
 {
-    const u64 outU = Hs[iu], outV = Hs[iv];
-    const u64 inU = ballot((myH >> iu) & 1ull), inV = ballot((myH >> iv) & 1ull);
-    const u64 nbm = ~((1ull << iu) | (1ull << iv));
-    const u64 P = inU & inV & nbm;    // w->u, w->v : before u
-    const u64 M = outU & inV & nbm;   // u->w, w->v : between
-    const u64 S = outU & outV & nbm;  // u->w, v->w : after v
+    const int s = k + 2;
+    const u64 uv = 3ull << k;
+    const u64 prim1 = c.M & ~c.P, prim2 = c.S & ~(c.P | c.M);
+    const u64 xm = c.P & c.M, xs = c.S & (c.P | c.M);  // vertices that also need an M node / an S node
+    u64 N1 = prim1, N2 = prim2;
+    u64 base = myH & ~uv;  // raw out-mask of the vertex this lane's node stands for
+    int cls = ((c.P >> lane) & 1ull) ? 0 : (((prim1 >> lane) & 1ull) ? 1 : (((prim2 >> lane) & 1ull) ? 2 : 3));
+    // pass 1: seat the extra nodes (wave-uniform loops, a handful of trips)
+    int r = 0;
+    for (u64 m = xm; m; m &= m - 1, ++r) {
+        const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
+        const u64 ho = rdlane64(myH, orig) & ~uv;
+        if (lane == pos) { base = ho; cls = 1; }
+        N1 |= 1ull << pos;
+    }
+    for (u64 m = xs; m; m &= m - 1, ++r) {
+        const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
+        const u64 ho = rdlane64(myH, orig) & ~uv;
+        if (lane == pos) { base = ho; cls = 2; }
+        N2 |= 1ull << pos;
+    }
+    // pass 2: a child vertex shows up at its own index and at each of its extras
+    u64 row = base & (c.P | prim1 | prim2);
+    r = 0;
+    for (u64 m = xm; m; m &= m - 1, ++r) {
+        const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
+        row |= ((base >> orig) & 1ull) << pos;
+    }
+    for (u64 m = xs; m; m &= m - 1, ++r) {
+        const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
+        row |= ((base >> orig) & 1ull) << pos;
+    }
+    // children must not come earlier in the P*M*S* order
+    const u64 G2 = N2, G1 = N1 | N2, G0 = c.P | G1;
+    row &= cls == 0 ? G0 : (cls == 1 ? G1 : (cls == 2 ? G2 : 0ull));
+    Hp[lane] = row;
+    wave_sync();
+    if (tmax >= 1 && cls != 3) delta[1] += sign;
     u32 dummy = 0;
-    eval_classes<MAXT, false>(myH, Hs, P, M, S, tmax, sign, lane, delta, dummy);
+    if (row) visit<1, MAXT, false>(row, Hp, tmax, sign, delta, dummy);
+    wave_sync();
 }
 
 // ---- the three evaluations a simple move is made of (fast path) -------------
-// K then big, small: lane k = big, lane k+1 = small.
+// K then big, small: lane k = big, lane k+1 = small.  Hs = raw masks, Hp = split
+// graph (both 64 u64 in LDS).  Each returns FCM_NEEDS_WIDE when the extras do
+// not fit; the caller then zeroes delta and redoes the proposal on the wide path.
 
 // single_edge_flip on undirected edge (big,small): returns 0 if the pair is
 // reciprocal (empty transition), 1 if big->small was flipped, 2 if small->big,
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
 __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
+                                         u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -251,29 +298,25 @@ __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u3
     Hs[lane] = myH;
     wave_sync();
     const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
-    int res;
-    if (ab == ba) {
-        res = ab ? 0 : -1;
-    } else {
-        const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;  // u->v present
-        eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta);
-        wave_sync();
-        if (lane == iu) { myH &= ~(1ull << iv); Hs[lane] = myH; }
-        if (lane == iv) { myH |= (1ull << iu); Hs[lane] = myH; }
-        wave_sync();
-        eval_edge<MAXT>(myH, Hs, iv, iu, tmax, +1, lane, delta);
-        res = ab ? 1 : 2;
-    }
-    wave_sync();
-    return res;
+    if (ab == ba) return ab ? 0 : -1;
+    const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;  // u->v present
+    Cls c = classify(myH, Hs, iu, iv);
+    // after the flip P and S are the same sets, M becomes {v->w, w->u}
+    Cls c2;
+    c2.P = c.P; c2.S = c.S;
+    c2.M = Hs[iv] & ballot((myH >> iu) & 1ull) & ~(3ull << k);
+    if (!extras_fit(c, s) || !extras_fit(c2, s)) return FCM_NEEDS_WIDE;
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
+    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta);
+    return ab ? 1 : 2;
 }
 
 // double_edge_move step 1: subtract the simplices through one direction of the
-// reciprocal pair (big,small).  coin=1 removes big->small.  Returns false if
+// reciprocal pair (big,small).  coin=1 removes big->small.  Returns 1, or 0 if
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
-__device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u32 coin, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
+__device__ __forceinline__ int del_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
+                                        u32 coin, u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -282,17 +325,18 @@ __device__ __forceinline__ bool del_eval(const u32 *rows, u32 stride32, const u3
     wave_sync();
     const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
     const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
-    eval_edge<MAXT>(myH, Hs, iu, iv, tmax, -1, lane, delta);
-    wave_sync();
-    return (ab & ba) != 0u;
+    const Cls c = classify(myH, Hs, iu, iv);
+    if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
+    return (ab & ba) ? 1 : 0;
 }
 
 // double_edge_move step 2: on the graph without dfrom->dto, add the reverse of
 // the single edge of (big,small) and add the simplices through it.  fwd=1
 // means big->small is the existing direction.
 template <int MAXT>
-__device__ __forceinline__ void add_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u32 fwd, u32 dfrom, u32 dto, u64 *Hs, int lane, int tmax, int (&delta)[MAXT + 1])
+__device__ __forceinline__ int add_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
+                                        u32 fwd, u32 dfrom, u32 dto, u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
     const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
@@ -307,8 +351,10 @@ __device__ __forceinline__ void add_eval(const u32 *rows, u32 stride32, const u3
     if (lane == ib) myH |= (1ull << ia);
     Hs[lane] = myH;
     wave_sync();
-    eval_edge<MAXT>(myH, Hs, ib, ia, tmax, +1, lane, delta);
-    wave_sync();
+    const Cls c = classify(myH, Hs, ib, ia);
+    if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, +1, lane, delta);
+    return 1;
 }
 
 // ===========================================================================
@@ -330,7 +376,7 @@ struct Wide {
 // u64 words of dynamic LDS a workgroup needs for local sets of up to 64*NW vertices
 __host__ __device__ inline unsigned fcm_lds_words(int NW)
 {
-    if (NW <= 1) return 64u;
+    if (NW <= 1) return 2u * 64u;  // Hs + Hp
     return 64u * NW * NW + 12u + FCM_WIDE_LEVELS * 8u + 16u + FCM_WIDE_LEVELS + 32u * NW;
 }
 __device__ __forceinline__ Wide wide_carve(u64 *smem, int NW)
@@ -572,7 +618,7 @@ template <int MAXT, int MINW>
 __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];  // fcm_lds_words(p.maxnw) words
-    u64 *Hs = smem;
+    u64 *Hs = smem, *Hp = smem + WAVE;  // fast path: raw masks and split graph; the wide path reuses the region
     const int lane = threadIdx.x;
     const u32 chain = blockIdx.x;
     if (chain >= p.nchains) return;
@@ -640,16 +686,17 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     const u32 a = rdlane(l_e.big, sidx), b = rdlane(l_e.small, sidx);
                     const u32 off = rdlane(l_e.nb_off, sidx);
                     const int k = (int)rdlane(l_e.k, sidx);
-                    int res;
-                    if (k + 2 <= WAVE) {
-                        res = flip_eval<MAXT>(rows, stride32, nb, off, k, a, b, Hs, lane, tmax, delta);
-                    } else if (k + 2 <= 64 * maxnw) {
-                        const Wide W = wide_carve(smem, maxnw);
-                        wide_zero_counts(W, lane);
-                        res = wide_flip(W, rows, stride32, nb, off, k, a, b, lane, tmax);
-                        used_wide = true;
-                    } else {
-                        res = -1;
+                    int res = FCM_NEEDS_WIDE;
+                    if (k + 2 <= WAVE) res = flip_eval<MAXT>(rows, stride32, nb, off, k, a, b, Hs, Hp, lane, tmax, delta);
+                    if (res == FCM_NEEDS_WIDE) {
+                        if (k + 2 <= 64 * maxnw) {
+                            const Wide W = wide_carve(smem, maxnw);
+                            wide_zero_counts(W, lane);
+                            res = wide_flip(W, rows, stride32, nb, off, k, a, b, lane, tmax);
+                            used_wide = true;
+                        } else {
+                            res = -1;
+                        }
                     }
                     if (res < 0) status |= 1u;  // table says adjacent, bitmap says not
                     if (res > 0) {
@@ -703,9 +750,22 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         const u32 dfrom = coin ? de.big : de.small, dto = coin ? de.small : de.big;
                         nonempty = true; is_dmove = true;
                         const int dk = (int)de.k;
-                        const bool any_wide = dk + 2 > WAVE || rk + 2 > WAVE;
+                        bool go_wide = dk + 2 > WAVE || rk + 2 > WAVE;
                         bool okd = true;
-                        if (any_wide) {
+                        if (!go_wide) {
+                            // (1) remove delme: subtract simplices through it
+                            const int r1 = del_eval<MAXT>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, Hp, lane, tmax, delta);
+                            go_wide = r1 == FCM_NEEDS_WIDE;
+                            okd = r1 != 0;
+                            if (!go_wide) {
+                                // (2) add eb->ea on the graph without delme: add simplices through it
+                                const int r2 = add_eval<MAXT>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, Hp, lane, tmax, delta);
+                                go_wide = r2 == FCM_NEEDS_WIDE;
+                            }
+                        }
+                        if (go_wide) {
+#pragma unroll
+                            for (int q = 0; q <= MAXT; ++q) delta[q] = 0;
                             if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
                                 status |= 1u;
                             } else {
@@ -715,11 +775,6 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                                 wide_add(W, rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, lane, tmax);
                                 used_wide = true;
                             }
-                        } else {
-                            // (1) remove delme: subtract simplices through it
-                            okd = del_eval<MAXT>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, lane, tmax, delta);
-                            // (2) add eb->ea on the graph without delme: add simplices through it
-                            add_eval<MAXT>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, lane, tmax, delta);
                         }
                         if (!okd) status |= 2u;  // slot list says reciprocal, bitmap says not
                         c_clr_from = dfrom; c_clr_to = dto;

@@ -273,9 +273,12 @@ def _book_graph(t, p_page, seed):
     return np.array(e, np.uint32)
 
 
-@pytest.mark.parametrize("t,p_page", [(66, 0.04), (100, 0.03), (129, 0.02), (200, 0.012)])
+@pytest.mark.parametrize("t,p_page", [(60, 0.04), (63, 0.04), (64, 0.04), (65, 0.04), (66, 0.04), (100, 0.03), (129, 0.02), (200, 0.012)])
 def test_wide_neighbourhoods(fcm, oracle, t, p_page):
-    """|N(a) cap N(b)| + 2 = t > 64: two or four mask words per local vertex."""
+    """|N(a) cap N(b)| + 2 = t around and above 64.  t > 64 needs two or four mask
+    words per local vertex (wide path); t <= 64 fits one word, but the per-class
+    copies of the many multi-class vertices of this graph do not fit in 64 nodes,
+    which exercises the fast path's fallback to the wide one."""
     e = _book_graph(t, p_page, seed=t)
     go = oracle.Graph.from_edges(t, e)
     assert fcm.Graph.from_edges(t, e).flagser_count() == go.flagser_count()
