@@ -663,6 +663,15 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         const u64 l_idx = __umul64hi(x64, l_move == 0 ? Mtot : (u64)D);
         FcmEdgeEntry l_e = {0u, 0u, 0u, 0u};
         if (l_move == 0 && l_idx < U) l_e = p.etab[l_idx];
+        // double-edge moves: the first two single-edge candidates (block sub=1)
+        // are drawn here too, once per 64 proposals instead of once per move
+        u64 l_c0 = 0ull, l_c1 = 0ull;
+        if (l_move == 1) {
+            u32 v[4];
+            philox4x32_10((u32)t, (u32)(t >> 32), gchain, 1u, k0, k1, v);
+            l_c0 = __umul64hi((u64)v[0] | ((u64)v[1] << 32), Mtot);
+            l_c1 = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
+        }
 
         const int nbatch = (int)min((u64)WAVE, p.nprop - done);
         for (int sidx = 0; sidx < nbatch; ++sidx) {
@@ -712,22 +721,24 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     const u32 slot = (u32)idx;
                     const u32 ed = dbl[slot];
                     const FcmEdgeEntry de = p.etab[ed];
-                    // Up to 64 candidate draws for the single edge, first valid wins
-                    // (uniform directed edge, retry while reciprocal: :308-313).
+                    // Up to 64 candidate draws for the single edge (two per Philox block
+                    // sub = 1..32), first valid in order wins (uniform directed edge, retry
+                    // while reciprocal: :308-313).  Candidates 0 and 1 come from the batch
+                    // draw and are probed by lanes 0 and 1; one of them is valid with
+                    // probability ~0.99, so the later blocks are almost never computed.
                     const u64 tt = sampled;  // this proposal's step index
-                    u32 v[4];
-                    philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(lane >> 1) + 1u, k0, k1, v);
-                    const u64 y64 = (lane & 1) ? ((u64)v[2] | ((u64)v[3] << 32)) : ((u64)v[0] | ((u64)v[1] << 32));
-                    const u64 rr = __umul64hi(y64, Mtot);
-                    // Probe the candidates four at a time (lanes base..base+3): one
-                    // is valid with probability ~0.9, so later groups are almost never
-                    // touched and the probe costs a dozen cache lines, not two hundred.
-                    // The winner is the first valid candidate in lane order either way.
+                    const u64 c0 = rdlane64(l_c0, sidx), c1 = rdlane64(l_c1, sidx);
+                    u64 rr = lane == 0 ? c0 : c1;
                     FcmEdgeEntry ce = {0u, 0u, 0u, 0u};
                     u32 fwd = 0;
                     u64 vm = 0ull;
-                    for (int base = 0; base < WAVE && vm == 0ull; base += 4) {
-                        bool valid = lane >= base && lane < base + 4 && rr < U;
+                    for (int base = 0; base < WAVE && vm == 0ull; base += 2) {
+                        if (base > 0) {  // rare: draw block sub = base/2 + 1 now
+                            u32 v[4];
+                            philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(base >> 1) + 1u, k0, k1, v);
+                            rr = __umul64hi((lane & 1) ? ((u64)v[2] | ((u64)v[3] << 32)) : ((u64)v[0] | ((u64)v[1] << 32)), Mtot);
+                        }
+                        bool valid = lane < 2 && rr < U;
                         if (valid) {
                             ce = p.etab[rr];
                             const u32 wf = rows[(size_t)ce.big * stride32 + (ce.small >> 5)];
