@@ -353,6 +353,16 @@ typedef struct {
     uint32_t *uedges;     /* 2 * n_uedges: big, small */
     uint64_t *nb_off;     /* n_uedges + 1 */
     uint32_t *nb;         /* concatenated neighbour lists (may hold duplicates, src/lib.rs:333-336) */
+    /* cliques_by_order (src/lib.rs:31,41-49): maximal cliques of pr(G) bucketed by
+     * order; bucket o-1 holds cl_count[o-1] cliques of o vertices each, stored
+     * back to back from cl_flat[cl_base[o-1]].  Canonical layout: vertices of a
+     * clique ascending, cliques of a bucket in lexicographic order.  Built on
+     * demand (only the clique moves read it). */
+    int cliques_ready;
+    int cl_orders;                      /* cliques_by_order.len() = largest order */
+    uint64_t cl_count[FO_MAXDIM];
+    uint64_t cl_base[FO_MAXDIM];
+    uint32_t *cl_flat;
 } fo_state;
 
 static int fo_cmp_u32(const void *a, const void *b)
@@ -427,8 +437,152 @@ void fo_state_free(fo_state *st)
 {
     if (!st) return;
     fo_graph_free(st->graph);
-    free(st->uedges); free(st->nb_off); free(st->nb);
+    free(st->uedges); free(st->nb_off); free(st->nb); free(st->cl_flat);
     free(st);
+}
+
+/* ------------------------------------------------------------------------ */
+/* compute_maximal_cliques (external crate, called at src/lib.rs:41): all      */
+/* maximal cliques of pr(G).  Bron-Kerbosch with pivoting over bitsets, one    */
+/* outer pass per smallest vertex.  The reference's enumeration order is       */
+/* unknown; it is irrelevant to the sampling distribution (cliques are picked  */
+/* uniformly, src/lib.rs:216) and the canonical order above replaces it.       */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    const uint64_t *und; uint32_t n, wq;
+    uint32_t R[FO_MAXDIM]; int rlen;
+    uint64_t *work;           /* (FO_MAXDIM+1) * 2 * wq words */
+    uint32_t *out; uint64_t out_len, out_cap;   /* records: len, v0..v(len-1) */
+    int err;
+} fo_bk;
+
+static void fo_bk_emit(fo_bk *b)
+{
+    if (b->out_len + (uint64_t)b->rlen + 1 > b->out_cap) {
+        uint64_t nc = b->out_cap ? b->out_cap * 2 : (1u << 20);
+        uint32_t *no = (uint32_t *)realloc(b->out, nc * sizeof(uint32_t));
+        if (!no) { b->err = 1; return; }
+        b->out = no; b->out_cap = nc;
+    }
+    b->out[b->out_len++] = (uint32_t)b->rlen;
+    for (int i = 0; i < b->rlen; ++i) b->out[b->out_len++] = b->R[i];
+}
+
+static void fo_bk_rec(fo_bk *b, uint64_t *P, uint64_t *X, int depth)
+{
+    const uint32_t wq = b->wq;
+    uint64_t anyP = 0, anyX = 0;
+    for (uint32_t q = 0; q < wq; ++q) { anyP |= P[q]; anyX |= X[q]; }
+    if (!anyP) { if (!anyX) fo_bk_emit(b); return; }
+    if (depth >= FO_MAXDIM - 1 || b->err) { b->err = 1; return; }
+    /* pivot: vertex of P|X with most neighbours in P */
+    int best = -1; uint32_t pivot = 0;
+    for (uint32_t q = 0; q < wq; ++q) {
+        uint64_t x = P[q] | X[q];
+        while (x) {
+            uint32_t u = q * 64 + (uint32_t)__builtin_ctzll(x); x &= x - 1;
+            const uint64_t *nu = b->und + (size_t)u * wq;
+            int c = 0;
+            for (uint32_t r = 0; r < wq; ++r) c += __builtin_popcountll(P[r] & nu[r]);
+            if (c > best) { best = c; pivot = u; }
+        }
+    }
+    uint64_t *nP = b->work + (size_t)(depth + 1) * 2 * wq, *nX = nP + wq;
+    const uint64_t *np = b->und + (size_t)pivot * wq;
+    for (uint32_t q = 0; q < wq; ++q) {
+        uint64_t cand = P[q] & ~np[q];
+        while (cand) {
+            uint32_t v = q * 64 + (uint32_t)__builtin_ctzll(cand); cand &= cand - 1;
+            const uint64_t *nv = b->und + (size_t)v * wq;
+            for (uint32_t r = 0; r < wq; ++r) { nP[r] = P[r] & nv[r]; nX[r] = X[r] & nv[r]; }
+            b->R[b->rlen++] = v;
+            fo_bk_rec(b, nP, nX, depth + 1);
+            b->rlen--;
+            P[q] &= ~(1ull << (v & 63));
+            X[q] |= 1ull << (v & 63);
+        }
+    }
+}
+
+static int fo_cmp_clique_o;  /* order of the bucket being sorted */
+static int fo_cmp_clique(const void *a, const void *b)
+{
+    const uint32_t *x = (const uint32_t *)a, *y = (const uint32_t *)b;
+    for (int i = 0; i < fo_cmp_clique_o; ++i) if (x[i] != y[i]) return x[i] < y[i] ? -1 : 1;
+    return 0;
+}
+
+int fo_state_ensure_cliques(fo_state *st)
+{
+    if (st->cliques_ready) return 0;
+    const fo_graph *g = st->graph;
+    const uint32_t n = g->n, wq = g->wq;
+    uint64_t *und = (uint64_t *)calloc((size_t)n * wq + 1, sizeof(uint64_t));
+    if (!und) return -1;
+    for (uint64_t e = 0; e < st->n_uedges; ++e) {
+        uint32_t a = st->uedges[2 * e], b = st->uedges[2 * e + 1];
+        und[(size_t)a * wq + (b >> 6)] |= 1ull << (b & 63);
+        und[(size_t)b * wq + (a >> 6)] |= 1ull << (a & 63);
+    }
+    fo_bk b; memset(&b, 0, sizeof b);
+    b.und = und; b.n = n; b.wq = wq;
+    b.work = (uint64_t *)malloc((size_t)(FO_MAXDIM + 1) * 2 * wq * sizeof(uint64_t));
+    if (!b.work) { free(und); return -1; }
+    for (uint32_t v = 0; v < n && !b.err; ++v) {
+        uint64_t *P = b.work, *X = b.work + wq;
+        const uint64_t *nv = und + (size_t)v * wq;
+        for (uint32_t q = 0; q < wq; ++q) {   /* later neighbours may extend, earlier ones exclude */
+            uint64_t lo = (q < (v >> 6)) ? ~0ull : (q == (v >> 6) ? ((1ull << (v & 63)) - 1ull) : 0ull);
+            X[q] = nv[q] & lo;
+            P[q] = nv[q] & ~lo & ~((q == (v >> 6)) ? (1ull << (v & 63)) : 0ull);
+        }
+        b.R[0] = v; b.rlen = 1;
+        fo_bk_rec(&b, P, X, 0);
+    }
+    free(b.work); free(und);
+    if (b.err) { free(b.out); return -1; }
+    /* bucket by order (src/lib.rs:42-49), canonical order inside a bucket */
+    memset(st->cl_count, 0, sizeof st->cl_count);
+    st->cl_orders = 0;
+    for (uint64_t i = 0; i < b.out_len; i += b.out[i] + 1) {
+        int o = (int)b.out[i];
+        st->cl_count[o - 1]++;
+        if (o > st->cl_orders) st->cl_orders = o;
+    }
+    uint64_t total = 0;
+    for (int o = 1; o <= st->cl_orders; ++o) { st->cl_base[o - 1] = total; total += st->cl_count[o - 1] * (uint64_t)o; }
+    st->cl_flat = (uint32_t *)malloc((total ? total : 1) * sizeof(uint32_t));
+    uint64_t fill[FO_MAXDIM]; memset(fill, 0, sizeof fill);
+    for (uint64_t i = 0; i < b.out_len; i += b.out[i] + 1) {
+        int o = (int)b.out[i];
+        uint32_t *dst = st->cl_flat + st->cl_base[o - 1] + fill[o - 1] * (uint64_t)o;
+        memcpy(dst, &b.out[i + 1], (size_t)o * sizeof(uint32_t));
+        qsort(dst, (size_t)o, sizeof(uint32_t), fo_cmp_u32);
+        fill[o - 1]++;
+    }
+    free(b.out);
+    for (int o = 1; o <= st->cl_orders; ++o) {
+        fo_cmp_clique_o = o;
+        qsort(st->cl_flat + st->cl_base[o - 1], st->cl_count[o - 1], (size_t)o * sizeof(uint32_t), fo_cmp_clique);
+    }
+    st->cliques_ready = 1;
+    return 0;
+}
+
+/* number of maximal cliques per order; returns cliques_by_order.len() */
+int fo_state_clique_counts(fo_state *st, uint64_t *out /* FO_MAXDIM */)
+{
+    if (fo_state_ensure_cliques(st)) return -1;
+    memcpy(out, st->cl_count, sizeof st->cl_count);
+    return st->cl_orders;
+}
+/* copies bucket `order` (order*count vertices) */
+int64_t fo_state_cliques_of_order(fo_state *st, int order, uint32_t *out, uint64_t cap)
+{
+    if (fo_state_ensure_cliques(st) || order < 1 || order > st->cl_orders) return -1;
+    uint64_t nn = st->cl_count[order - 1] * (uint64_t)order;
+    if (out) memcpy(out, st->cl_flat + st->cl_base[order - 1], (size_t)(nn < cap ? nn : cap) * sizeof(uint32_t));
+    return (int64_t)st->cl_count[order - 1];
 }
 
 fo_graph *fo_state_graph(fo_state *st) { return st->graph; }
@@ -482,10 +636,11 @@ int64_t fo_state_edgeset_neighborhood(const fo_state *st, const uint32_t *edges,
 }
 
 /* Transition (src/lib.rs:200-204): change_edges = ([from,to], add?) */
+#define FO_MAX_CHANGES 1024 /* clique_swap on two 16-cliques changes at most 2*16*15 edges */
 typedef struct {
-    uint32_t n;            /* 0 or 2 for the simple moves */
-    uint32_t edge[4][2];
-    int add[4];
+    uint32_t n;            /* 0 or 2 for the simple moves, up to order^2 for the clique moves */
+    uint32_t edge[FO_MAX_CHANGES][2];
+    int add[FO_MAX_CHANGES];
 } fo_transition;
 
 typedef struct {
@@ -497,7 +652,7 @@ typedef struct {
  * `assert!(*s >= *p)` would fire. */
 int fo_state_apply_transition(fo_state *st, const fo_transition *t, fo_counters *c)
 {
-    uint32_t norm[8];
+    static __thread uint32_t norm[2 * FO_MAX_CHANGES];
     for (uint32_t i = 0; i < t->n; ++i) {
         uint32_t a = t->edge[i][0], b = t->edge[i][1];
         norm[2 * i] = a > b ? a : b; norm[2 * i + 1] = a > b ? b : a;
@@ -547,8 +702,8 @@ int fo_state_revert_transition(fo_state *st, const fo_transition *t, const fo_co
 int fo_state_apply_flat(fo_state *st, uint32_t n, const uint32_t *edges, const int *add,
                         uint64_t *pre, int *pre_len, uint64_t *post, int *post_len)
 {
-    fo_transition t; fo_counters c;
-    if (n > 4) return -3;
+    static __thread fo_transition t; fo_counters c;
+    if (n > FO_MAX_CHANGES) return -3;
     t.n = n;
     for (uint32_t i = 0; i < n; ++i) { t.edge[i][0] = edges[2 * i]; t.edge[i][1] = edges[2 * i + 1]; t.add[i] = add[i]; }
     int rc = fo_state_apply_transition(st, &t, &c);
@@ -560,8 +715,8 @@ int fo_state_apply_flat(fo_state *st, uint32_t n, const uint32_t *edges, const i
 int fo_state_revert_flat(fo_state *st, uint32_t n, const uint32_t *edges, const int *add,
                          const uint64_t *pre, int pre_len, const uint64_t *post, int post_len)
 {
-    fo_transition t; fo_counters c;
-    if (n > 4) return -3;
+    static __thread fo_transition t; fo_counters c;
+    if (n > FO_MAX_CHANGES) return -3;
     t.n = n;
     for (uint32_t i = 0; i < n; ++i) { t.edge[i][0] = edges[2 * i]; t.edge[i][1] = edges[2 * i + 1]; t.add[i] = add[i]; }
     memcpy(c.pre, pre, sizeof c.pre); c.pre_len = pre_len;
@@ -667,7 +822,13 @@ typedef struct {
     uint64_t n_empty;     /* proposals with an empty transition */
     uint64_t n_flip, n_dmove; /* non-empty proposals by kind */
     uint64_t sum_k;       /* sum over evaluated edges of |N(a) cap N(b)| (dedup'd) */
+    /* clique moves (src/lib.rs:214-290) */
+    uint64_t cumo[FO_MAXDIM];  /* clique_order_distribution (src/bin/sample.rs:87-88) as 2^32-scaled thresholds */
+    uint64_t n_cperm, n_cswap; /* non-empty clique_permute / clique_swap proposals */
+    uint64_t n_changes;        /* directed edges changed by clique moves (proposed) */
 } fo_chain;
+
+void fo_chain_free(fo_chain *c);
 
 #define FO_MAX_SUB 32 /* philox blocks tried for the single edge of a double-edge move */
 
@@ -699,6 +860,22 @@ fo_chain *fo_chain_new(const fo_graph *g, const fo_bounds *bounds, const double 
     fo_move_thresholds(weights, c->cum);
     c->sample_distance = sample_distance;
     c->seed = seed; c->chain_id = chain_id;
+    if (weights[2] > 0.0 || weights[3] > 0.0) {
+        /* clique_order_distribution: weights (#cliques of the order)^0.2 (src/bin/sample.rs:87-88) */
+        if (fo_state_ensure_cliques(c->state)) { fo_chain_free(c); return NULL; }
+        double tot = 0, acc = 0;
+        int last = 0;
+        for (int o = 0; o < c->state->cl_orders; ++o) {
+            double wgt = pow((double)c->state->cl_count[o], 0.2);
+            tot += wgt;
+            if (wgt > 0.0) last = o;
+        }
+        for (int o = 0; o < c->state->cl_orders; ++o) {
+            acc += pow((double)c->state->cl_count[o], 0.2);
+            c->cumo[o] = (uint64_t)floor(4294967296.0 * (acc / tot));
+        }
+        for (int o = last; o < FO_MAXDIM; ++o) c->cumo[o] = 4294967296ull;
+    }
     /* reciprocal pairs in ascending undirected-edge order */
     uint64_t nd = 0;
     for (uint64_t e = 0; e < c->state->n_uedges; ++e) {
@@ -724,10 +901,11 @@ void fo_chain_free(fo_chain *c)
 }
 
 fo_state *fo_chain_state(fo_chain *c) { return c->state; }
-void fo_chain_stats(const fo_chain *c, uint64_t out[6])
+void fo_chain_stats(const fo_chain *c, uint64_t out[9])
 {
     out[0] = c->sampled; out[1] = c->accepted; out[2] = c->n_empty;
     out[3] = c->n_flip; out[4] = c->n_dmove; out[5] = c->sum_k;
+    out[6] = c->n_cperm; out[7] = c->n_cswap; out[8] = c->n_changes;
 }
 uint64_t fo_chain_n_double(const fo_chain *c) { return c->n_double; }
 const uint64_t *fo_chain_dbl(const fo_chain *c) { return c->dbl; }
@@ -738,6 +916,44 @@ static uint64_t fo_dedup_k(const fo_state *st, uint64_t e)
     for (uint64_t q = st->nb_off[e]; q < st->nb_off[e + 1]; ++q)
         if (q == st->nb_off[e] || st->nb[q] != st->nb[q - 1]) ++k;
     return k;
+}
+
+/* 32-bit words for the shuffles of the clique moves: Philox blocks sub = 2, 3, ... */
+typedef struct { uint32_t key[2]; uint32_t ctr[4]; uint32_t w[4]; int pos; } fo_words;
+static uint32_t fo_next_word(fo_words *s)
+{
+    if (s->pos == 4) { fo_philox4x32_10(s->ctr, s->key, s->w); s->ctr[3]++; s->pos = 0; }
+    return s->w[s->pos++];
+}
+/* random_perm (src/util.rs:28-32): l..h shuffled.  Fisher-Yates from the top,
+ * j = floor(word * (i+1) / 2^32)  (rand's `shuffle`; draw spec in DESIGN.md). */
+static void fo_random_perm(uint32_t l, uint32_t h, fo_words *ws, uint32_t *out)
+{
+    uint32_t len = h - l;
+    for (uint32_t i = 0; i < len; ++i) out[i] = l + i;
+    for (uint32_t i = len; i-- > 1;) {
+        uint32_t j = (uint32_t)(((uint64_t)fo_next_word(ws) * (uint64_t)(i + 1)) >> 32);
+        uint32_t tmp = out[i]; out[i] = out[j]; out[j] = tmp;
+    }
+}
+static int fo_cmp_edge(const void *a, const void *b)
+{
+    const uint32_t *x = (const uint32_t *)a, *y = (const uint32_t *)b;
+    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    if (x[1] != y[1]) return x[1] < y[1] ? -1 : 1;
+    return 0;
+}
+static uint32_t fo_sort_dedup_edges(uint32_t (*e)[2], uint32_t n)
+{
+    qsort(e, n, sizeof e[0], fo_cmp_edge);
+    uint32_t u = 0;
+    for (uint32_t i = 0; i < n; ++i) if (u == 0 || fo_cmp_edge(e[u - 1], e[i]) != 0) { e[u][0] = e[i][0]; e[u][1] = e[i][1]; ++u; }
+    return u;
+}
+static int fo_cmp_u64(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
 }
 
 /* One proposal = one iteration of MCMCSampler::next's loop (src/lib.rs:182-192).
@@ -757,8 +973,12 @@ static int fo_chain_propose(fo_chain *c)
     int coin = (int)(w[1] & 1u);
     uint64_t x64 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
 
-    fo_transition t; t.n = 0;
+    static __thread fo_transition t; t.n = 0;
     uint64_t dbl_slot = 0, new_double_edge = 0; int is_dmove = 0;
+    int move_kind = move;                      /* 2 = clique_permute, 3 = clique_swap */
+    static __thread uint64_t touched[FO_MAX_CHANGES];
+    static __thread uint8_t was_double[FO_MAX_CHANGES];
+    uint32_t n_touched = 0;
 
     if (move == 0) {
         /* single_edge_flip (src/lib.rs:292-299): uniform directed edge; flip
@@ -816,17 +1036,138 @@ static int fo_chain_propose(fo_chain *c)
             }
         }
     } else {
-        return -10; /* clique moves: SURVEY.md 8(f) "next", not built */
+        /* clique_permute (src/lib.rs:214-232) / clique_swap (:234-290) */
+        if (fo_state_ensure_cliques(st)) return -12;
+        int oi = 0;
+        while (oi < st->cl_orders - 1 && (uint64_t)w[1] >= c->cumo[oi]) ++oi;   /* clique_order_distribution.sample */
+        const uint32_t order = (uint32_t)oi + 1;
+        const uint64_t cnt_o = st->cl_count[oi];
+        if (cnt_o == 0) return -13;
+        const uint32_t *m1 = st->cl_flat + st->cl_base[oi] + fo_mulhi64(x64, cnt_o) * order;   /* choose(rng) */
+        fo_words ws;
+        ws.key[0] = key[0]; ws.key[1] = key[1];
+        ws.ctr[0] = ctr[0]; ws.ctr[1] = ctr[1]; ws.ctr[2] = ctr[2]; ws.ctr[3] = 2; ws.pos = 4;
+        if (move == 2) {
+            uint32_t perm[FO_MAXDIM];
+            fo_random_perm(0, order, &ws, perm);
+            for (uint32_t i = 0; i < order; ++i)
+                for (uint32_t j = 0; j < order; ++j) {
+                    int pre = fo_graph_has_edge(st->graph, m1[perm[i]], m1[perm[j]]);
+                    int post = fo_graph_has_edge(st->graph, m1[i], m1[j]);
+                    if (pre != post) {
+                        if (t.n >= FO_MAX_CHANGES) return -14;
+                        t.edge[t.n][0] = m1[perm[i]]; t.edge[t.n][1] = m1[perm[j]]; t.add[t.n] = post; ++t.n;
+                    }
+                }
+            move_kind = 2;
+        } else {
+            uint32_t c1[4] = { ctr[0], ctr[1], ctr[2], 1 }, v[4];
+            fo_philox4x32_10(c1, key, v);
+            const uint32_t *m2 = st->cl_flat + st->cl_base[oi] + fo_mulhi64((uint64_t)v[0] | ((uint64_t)v[1] << 32), cnt_o) * order;
+            uint32_t d[2 * FO_MAXDIM], n_c = 0, n_d = 0;
+            for (uint32_t i = 0; i < order; ++i) {              /* c = vec_intersect(m1, m2) */
+                int in2 = 0;
+                for (uint32_t j = 0; j < order; ++j) if (m2[j] == m1[i]) in2 = 1;
+                if (in2) d[n_d++] = m1[i];
+            }
+            n_c = n_d;
+            for (uint32_t i = 0; i < order; ++i) {              /* m1 - c */
+                int inc = 0;
+                for (uint32_t j = 0; j < n_c; ++j) if (d[j] == m1[i]) inc = 1;
+                if (!inc) d[n_d++] = m1[i];
+            }
+            for (uint32_t i = 0; i < order; ++i) {              /* m2 - c */
+                int inc = 0;
+                for (uint32_t j = 0; j < n_c; ++j) if (d[j] == m2[i]) inc = 1;
+                if (!inc) d[n_d++] = m2[i];
+            }
+            const uint32_t n_a = order - n_c;
+            uint32_t perm_c[FO_MAXDIM], perm_a[FO_MAXDIM], perm_b[FO_MAXDIM], perm_d[2 * FO_MAXDIM];
+            fo_random_perm(0, n_c, &ws, perm_c);
+            fo_random_perm(n_c, n_c + n_a, &ws, perm_a);
+            fo_random_perm(n_c + n_a, n_d, &ws, perm_b);
+            uint32_t q = 0;
+            for (uint32_t i = 0; i < n_c; ++i) perm_d[q++] = perm_c[i];
+            for (uint32_t i = 0; i < n_d - n_c - n_a; ++i) perm_d[q++] = perm_b[i];
+            for (uint32_t i = 0; i < n_a; ++i) perm_d[q++] = perm_a[i];
+            static __thread uint32_t new_e[FO_MAX_CHANGES][2], old_e[FO_MAX_CHANGES][2];
+            uint32_t nn = 0, no = 0;
+            for (int pass = 0; pass < 2; ++pass) {              /* m1's range, then c + m2's range (:256-271) */
+                uint32_t idx[2 * FO_MAXDIM], ni = 0;
+                if (pass == 0) { for (uint32_t i = 0; i < n_c + n_a; ++i) idx[ni++] = i; }
+                else { for (uint32_t i = 0; i < n_c; ++i) idx[ni++] = i; for (uint32_t i = n_c + n_a; i < n_d; ++i) idx[ni++] = i; }
+                for (uint32_t a = 0; a < ni; ++a)
+                    for (uint32_t b = 0; b < ni; ++b) {
+                        uint32_t i = idx[a], j = idx[b];
+                        if (fo_graph_has_edge(st->graph, d[i], d[j])) {
+                            if (nn >= FO_MAX_CHANGES) return -14;
+                            new_e[nn][0] = d[perm_d[i]]; new_e[nn][1] = d[perm_d[j]]; ++nn;
+                            old_e[no][0] = d[i]; old_e[no][1] = d[j]; ++no;
+                        }
+                    }
+            }
+            nn = fo_sort_dedup_edges(new_e, nn);
+            no = fo_sort_dedup_edges(old_e, no);
+            uint8_t keep_old[FO_MAX_CHANGES];
+            memset(keep_old, 1, no);
+            for (uint32_t i = 0; i < nn; ++i) {
+                int found = 0;
+                for (uint32_t j = 0; j < no; ++j) if (keep_old[j] && fo_cmp_edge(new_e[i], old_e[j]) == 0) { keep_old[j] = 0; found = 1; }
+                if (!found) { t.edge[t.n][0] = new_e[i][0]; t.edge[t.n][1] = new_e[i][1]; t.add[t.n] = 1; ++t.n; }
+            }
+            for (uint32_t j = 0; j < no; ++j)
+                if (keep_old[j]) { if (t.n >= FO_MAX_CHANGES) return -14; t.edge[t.n][0] = old_e[j][0]; t.edge[t.n][1] = old_e[j][1]; t.add[t.n] = 0; ++t.n; }
+            move_kind = 3;
+        }
+        /* bookkeeping shared with the device: pairs touched, which of them are reciprocal now */
+        for (uint32_t i = 0; i < t.n; ++i) {
+            uint32_t a = t.edge[i][0], b = t.edge[i][1];
+            int64_t e = fo_state_uedge_index(st, a > b ? a : b, a > b ? b : a);
+            if (e < 0) return -2;
+            touched[n_touched++] = (uint64_t)e;
+            c->sum_k += fo_dedup_k(st, (uint64_t)e);
+        }
+        c->n_changes += t.n;
+        qsort(touched, n_touched, sizeof(uint64_t), fo_cmp_u64);
+        uint32_t u = 0;
+        for (uint32_t i = 0; i < n_touched; ++i) if (u == 0 || touched[u - 1] != touched[i]) touched[u++] = touched[i];
+        n_touched = u;
+        for (uint32_t i = 0; i < n_touched; ++i) {
+            uint32_t a = st->uedges[2 * touched[i]], b = st->uedges[2 * touched[i] + 1];
+            was_double[i] = (uint8_t)(fo_graph_has_edge(st->graph, a, b) && fo_graph_has_edge(st->graph, b, a));
+        }
     }
 
     fo_counters cnt;
     int rc = fo_state_apply_transition(st, &t, &cnt);       /* src/lib.rs:184 */
     if (rc) return rc;
     c->sampled += 1;                                         /* :185 */
-    if (t.n == 0) c->n_empty++; else if (is_dmove) c->n_dmove++; else c->n_flip++;
+    if (t.n == 0) c->n_empty++;
+    else if (move_kind == 2) c->n_cperm++;
+    else if (move_kind == 3) c->n_cswap++;
+    else if (is_dmove) c->n_dmove++;
+    else c->n_flip++;
     if (fo_bounds_check(&c->bounds, st->flag_count, st->flag_count_len)) {  /* :186 */
         c->accepted += 1;                                    /* :187 */
         if (is_dmove) c->dbl[dbl_slot] = new_double_edge;
+        if (move_kind >= 2 && t.n > 0) {
+            /* reciprocal-pair slot list: the i-th pair (ascending id) that stopped being
+             * reciprocal hands its slot to the i-th pair that became reciprocal */
+            uint64_t lost[FO_MAX_CHANGES], gained[FO_MAX_CHANGES]; uint32_t nl = 0, ng = 0;
+            for (uint32_t i = 0; i < n_touched; ++i) {
+                uint32_t a = st->uedges[2 * touched[i]], b = st->uedges[2 * touched[i] + 1];
+                int is = fo_graph_has_edge(st->graph, a, b) && fo_graph_has_edge(st->graph, b, a);
+                if (was_double[i] && !is) lost[nl++] = touched[i];
+                if (!was_double[i] && is) gained[ng++] = touched[i];
+            }
+            if (nl != ng) return -11;
+            for (uint32_t i = 0; i < nl; ++i) {
+                uint64_t slot = 0;
+                while (slot < c->n_double && c->dbl[slot] != lost[i]) ++slot;
+                if (slot == c->n_double) return -11;
+                c->dbl[slot] = gained[i];
+            }
+        }
     } else {
         rc = fo_state_revert_transition(st, &t, &cnt);       /* :190 */
         if (rc) return rc;

@@ -81,6 +81,8 @@ def lib():
         "fo_state_uedges": (u32p, [vp]),
         "fo_state_edge_neighborhood": (C.c_int64, [vp, C.c_uint32, C.c_uint32, u32p, C.c_uint64]),
         "fo_state_edgeset_neighborhood": (C.c_int64, [vp, u32p, C.c_uint32, u32p, C.c_uint64]),
+        "fo_state_clique_counts": (C.c_int, [vp, u64p]),
+        "fo_state_cliques_of_order": (C.c_int64, [vp, C.c_int, u32p, C.c_uint64]),
         "fo_state_apply_flat": (C.c_int, [vp, C.c_uint32, u32p, i32p, u64p, i32p, u64p, i32p]),
         "fo_state_revert_flat": (C.c_int, [vp, C.c_uint32, u32p, i32p, u64p, C.c_int, u64p, C.c_int]),
         "fo_target_bounds": (None, [u64p, C.c_int, C.c_double, C.POINTER(Bounds)]),
@@ -247,6 +249,22 @@ class State:
         p = lib().fo_state_uedges(self._h)
         return np.ctypeslib.as_array(p, shape=(max(n, 1), 2))[:n].copy()
 
+    def clique_counts(self):
+        """cliques_by_order[i].len() for i = 0.. (src/lib.rs:42-49; printed at sample.rs:85)"""
+        out = np.zeros(MAXDIM, np.uint64)
+        n = lib().fo_state_clique_counts(self._h, out.ctypes.data_as(u64p))
+        if n < 0:
+            raise MemoryError
+        return [int(x) for x in out[:n]]
+
+    def cliques_of_order(self, order):
+        cnt = lib().fo_state_cliques_of_order(self._h, order, None, 0)
+        if cnt < 0:
+            raise KeyError(order)
+        out = np.zeros((max(cnt, 1), order), np.uint32)
+        lib().fo_state_cliques_of_order(self._h, order, out.ctypes.data_as(u32p), cnt * order)
+        return out[:cnt]
+
     def edge_neighborhood(self, a, b):
         out = np.zeros(self_cap(self), np.uint32)
         n = lib().fo_state_edge_neighborhood(self._h, a, b, out.ctypes.data_as(u32p), len(out))
@@ -328,6 +346,7 @@ def move_thresholds(weights):
 
 
 SIMPLE_WEIGHTS = (0.5, 0.5, 0.0, 0.0)  # src/bin/sample.rs:16
+DEFAULT_WEIGHTS = (0.1, 0.1, 0.6, 0.2)  # src/bin/sample.rs:17
 
 
 class Chain:
@@ -357,9 +376,10 @@ class Chain:
         return self.state
 
     def stats(self):
-        out = np.zeros(6, np.uint64)
+        out = np.zeros(9, np.uint64)
         lib().fo_chain_stats(self._h, out.ctypes.data_as(u64p))
-        return dict(zip(("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k"), (int(x) for x in out)))
+        return dict(zip(("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes"),
+                        (int(x) for x in out)))
 
     def dbl(self):
         n = lib().fo_chain_n_double(self._h)
