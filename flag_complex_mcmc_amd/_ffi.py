@@ -12,8 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfcm.so")
 
 MAX_COUNTS = 16
-NSTATS = 8
-STAT_NAMES = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "count_len", "status")
+NSTATS = 12
+STAT_NAMES = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "count_len", "status",
+              "n_cperm", "n_cswap", "n_changes", "reserved")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_PANIC, ERR_NOMEM, ERR_INTERNAL = range(9)
 

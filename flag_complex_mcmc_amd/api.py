@@ -23,7 +23,7 @@ from . import _ffi
 from ._ffi import CBounds, CSamplerConfig, CSamplerInfo, FcmError, check, lib, u32p, u64p, i32p
 
 MOVE_DISTRIBUTION_SIMPLE = (0.5, 0.5, 0.0, 0.0)  # src/bin/sample.rs:16
-MOVE_DISTRIBUTION = (0.1, 0.1, 0.6, 0.2)         # src/bin/sample.rs:17 (clique moves: not built yet)
+MOVE_DISTRIBUTION = (0.1, 0.1, 0.6, 0.2)         # src/bin/sample.rs:17
 
 
 def _u32(a):

@@ -110,14 +110,17 @@ __global__ __launch_bounds__(256) void fcm_broadcast_rows_kernel(uint4 *__restri
 // Launchers
 // ---------------------------------------------------------------------------
 extern "C" {
-int fcm_launch_step_6(const FcmStepParams *, void *);
-int fcm_launch_step_14(const FcmStepParams *, void *);
+int fcm_launch_step_6_0(const FcmStepParams *, void *);
+int fcm_launch_step_14_0(const FcmStepParams *, void *);
+int fcm_launch_step_6_1(const FcmStepParams *, void *);
+int fcm_launch_step_14_1(const FcmStepParams *, void *);
 }
 
-// maxt: 6 (<= 8 count entries) or 14
-extern "C" int fcm_launch_step(const FcmStepParams *p, int maxt, void *stream)
+// maxt: 6 (<= 8 count entries) or 14; clique: kernel variant with the clique moves
+extern "C" int fcm_launch_step(const FcmStepParams *p, int maxt, int clique, void *stream)
 {
-    return maxt <= 6 ? fcm_launch_step_6(p, stream) : fcm_launch_step_14(p, stream);
+    if (clique) return maxt <= 6 ? fcm_launch_step_6_1(p, stream) : fcm_launch_step_14_1(p, stream);
+    return maxt <= 6 ? fcm_launch_step_6_0(p, stream) : fcm_launch_step_14_0(p, stream);
 }
 
 extern "C" int fcm_launch_count(const FcmCountParams *p, void *stream)

@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 #define FCM_DEV_MAX_COUNTS 16
-#define FCM_DEV_NSTATS 8
+#define FCM_DEV_NSTATS 12
 #define FCM_MAX_SUB 32           // philox blocks (2 candidates each) tried for the single edge of a double-edge move
 #define FCM_LAUNCH_CHUNK (1u << 16)  // proposals per chain per kernel launch
 
@@ -34,6 +34,16 @@ struct FcmStepParams {
     uint64_t nprop;            // proposals to run in this launch
     uint64_t rows_per_chain;   // n * stride32 (u32 words)
     uint32_t n, stride32, U, D, dbl_stride, first_chain, nchains;
+    // clique moves (reference src/lib.rs:214-290); all zero / null when their weights are 0
+    const uint32_t *clq;       // maximal cliques of pr(G): bucket o-1 = cl_count[o-1] cliques of o vertices from clq[cl_base[o-1]]
+    const uint32_t *efirst;    // [n+1] first etab index whose `big` is v (etab is sorted by (big, small))
+    uint32_t *slot_of;         // [n_chains][U] inverse of dbl: slot of a reciprocal pair, 0xFFFFFFFF otherwise
+    uint64_t cl_base[FCM_DEV_MAX_COUNTS];
+    uint64_t cl_count[FCM_DEV_MAX_COUNTS];
+    uint64_t cumo[FCM_DEV_MAX_COUNTS];   // clique_order_distribution as 2^32-scaled thresholds (sample.rs:87-88)
+    uint64_t cum2;             // clique_permute if w0 < cum2, else clique_swap
+    int32_t cl_orders;         // cliques_by_order.len()
+    uint32_t chg_cap;          // capacity of the change list in LDS (entries)
     int32_t ncounts;           // tracked count entries NC (<= 16)
     int32_t maxnw;             // mask words the largest local set needs: ceil((k_max+2)/64), 1..4
 };
@@ -51,7 +61,7 @@ struct FcmCountParams {
 extern "C" {
 #endif
 // launchers implemented in fcm_kernels.hip; `stream` is a hipStream_t
-int fcm_launch_step(const FcmStepParams *p, int maxt, void *stream);
+int fcm_launch_step(const FcmStepParams *p, int maxt, int clique, void *stream);
 int fcm_launch_count(const FcmCountParams *p, void *stream);
 int fcm_launch_broadcast_rows(uint32_t *rows, const uint32_t *base, uint64_t words_per_chain, uint32_t nchains, void *stream);
 #ifdef __cplusplus

@@ -524,6 +524,115 @@ extern "C" uint64_t fcm_default_sample_distance(uint64_t nedges)
 }
 
 // ---------------------------------------------------------------------------
+// Maximal cliques of pr(G): `compute_maximal_cliques` (external crate, called
+// at src/lib.rs:41) and the bucketing by order (src/lib.rs:42-49).  Tomita-
+// style pivoting on bitset rows.  Layout handed to the device: bucket o-1 =
+// all maximal cliques of o vertices, each clique ascending, the bucket in
+// lexicographic order (the reference's enumeration order is unknown and, as
+// cliques are drawn uniformly, immaterial).
+// ---------------------------------------------------------------------------
+struct CliqueTable {
+    int orders = 0;                                   // cliques_by_order.len()
+    uint64_t count[FCM_MAX_COUNTS] = {0}, base[FCM_MAX_COUNTS] = {0};
+    std::vector<uint32_t> flat;
+};
+
+namespace {
+struct CliqueFinder {
+    const std::vector<uint32_t> &und;                 // undirected bitmap, stride32 words per row
+    uint32_t n, stride, nw;
+    std::vector<std::vector<uint32_t>> byorder;       // flat vertex lists per order
+    std::vector<uint32_t> R;
+    bool too_deep = false;
+
+    CliqueFinder(const std::vector<uint32_t> &u, uint32_t n_, uint32_t stride_) : und(u), n(n_), stride(stride_), nw((n_ + 31) / 32) {}
+    const uint32_t *row(uint32_t v) const { return &und[(size_t)v * stride]; }
+
+    void expand(std::vector<uint32_t> &P, std::vector<uint32_t> &X)
+    {
+        bool anyP = false, anyX = false;
+        for (uint32_t w = 0; w < nw; ++w) { anyP |= P[w] != 0; anyX |= X[w] != 0; }
+        if (!anyP) {
+            if (!anyX) {
+                if (R.size() > FCM_MAX_COUNTS) { too_deep = true; return; }
+                if (byorder.size() < R.size()) byorder.resize(R.size());
+                std::vector<uint32_t> c(R);
+                std::sort(c.begin(), c.end());
+                byorder[R.size() - 1].insert(byorder[R.size() - 1].end(), c.begin(), c.end());
+            }
+            return;
+        }
+        if (too_deep || R.size() > FCM_MAX_COUNTS) { too_deep = true; return; }
+        // pivot with the most neighbours inside P
+        int best = -1;
+        uint32_t pivot = 0;
+        for (uint32_t w = 0; w < nw; ++w) {
+            uint32_t x = P[w] | X[w];
+            while (x) {
+                const uint32_t u = w * 32 + (uint32_t)__builtin_ctz(x);
+                x &= x - 1;
+                const uint32_t *ru = row(u);
+                int c = 0;
+                for (uint32_t q = 0; q < nw; ++q) c += __builtin_popcount(P[q] & ru[q]);
+                if (c > best) { best = c; pivot = u; }
+            }
+        }
+        const uint32_t *rp = row(pivot);
+        std::vector<uint32_t> nP(nw), nX(nw);
+        for (uint32_t w = 0; w < nw; ++w) {
+            uint32_t cand = P[w] & ~rp[w];
+            while (cand) {
+                const uint32_t v = w * 32 + (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1;
+                const uint32_t *rv = row(v);
+                for (uint32_t q = 0; q < nw; ++q) { nP[q] = P[q] & rv[q]; nX[q] = X[q] & rv[q]; }
+                R.push_back(v);
+                expand(nP, nX);
+                R.pop_back();
+                P[w] &= ~(1u << (v & 31));
+                X[w] |= 1u << (v & 31);
+            }
+        }
+    }
+};
+}  // namespace
+
+static int maximal_cliques(const fcm_graph &g, const std::vector<uint32_t> &und, CliqueTable &out)
+{
+    CliqueFinder f(und, g.n, g.stride32);
+    std::vector<uint32_t> P(f.nw), X(f.nw);
+    for (uint32_t v = 0; v < g.n; ++v) {   // v = smallest vertex of the clique
+        const uint32_t *rv = f.row(v);
+        for (uint32_t w = 0; w < f.nw; ++w) {
+            const uint32_t below = w < (v >> 5) ? 0xFFFFFFFFu : (w == (v >> 5) ? ((1u << (v & 31)) - 1u) : 0u);
+            X[w] = rv[w] & below;
+            P[w] = rv[w] & ~below;
+        }
+        f.R.assign(1, v);
+        f.expand(P, X);
+        if (f.too_deep) return fail(FCM_ERR_UNSUPPORTED, "pr(G) has a clique of more than %d vertices", FCM_MAX_COUNTS);
+    }
+    out.orders = (int)f.byorder.size();
+    uint64_t total = 0;
+    for (int o = 1; o <= out.orders; ++o) {
+        std::vector<uint32_t> &b = f.byorder[o - 1];
+        const size_t cnt = b.size() / o;
+        // lexicographic order of the bucket
+        std::vector<size_t> idx(cnt);
+        for (size_t i = 0; i < cnt; ++i) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) {
+            return std::lexicographical_compare(b.begin() + x * o, b.begin() + (x + 1) * o, b.begin() + y * o, b.begin() + (y + 1) * o);
+        });
+        out.count[o - 1] = cnt;
+        out.base[o - 1] = total;
+        for (size_t i = 0; i < cnt; ++i) out.flat.insert(out.flat.end(), b.begin() + idx[i] * o, b.begin() + (idx[i] + 1) * o);
+        total += (uint64_t)cnt * o;
+        std::vector<uint32_t>().swap(b);
+    }
+    return FCM_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Sampler
 // ---------------------------------------------------------------------------
 struct fcm_sampler {
@@ -536,7 +645,8 @@ struct fcm_sampler {
     uint32_t n = 0, stride32 = 0;
     std::vector<uint32_t> ue;          // [U][2] big, small
     // device buffers
-    DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats;
+    DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats, d_clq, d_efirst, d_slot_of;
+    bool clique_moves = false;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -572,8 +682,6 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
             return fail(FCM_ERR_INVALID, "move weight %d is negative or not finite", i);
     if (cfg->move_weights[0] + cfg->move_weights[1] + cfg->move_weights[2] + cfg->move_weights[3] <= 0.0)
         return fail(FCM_ERR_INVALID, "all move weights are zero");
-    if (cfg->move_weights[2] != 0.0 || cfg->move_weights[3] != 0.0)
-        return fail(FCM_ERR_UNSUPPORTED, "clique_permute / clique_swap moves are not built yet; use the --simple weights [w0,w1,0,0]");
     if (bounds->min_len < 0 || bounds->min_len > FCM_MAX_COUNTS || bounds->max_len < 0 || bounds->max_len > FCM_MAX_COUNTS)
         return fail(FCM_ERR_UNSUPPORTED, "bounds longer than %d entries", FCM_MAX_COUNTS);
     int rc = use_device(cfg->device);
@@ -674,6 +782,41 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
         HIP_TRY(hipMemcpy(s->d_counts.p, hc.data(), hc.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s->d_stats.p, hs.data(), hs.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
+    // --- clique moves: maximal cliques, order thresholds, pair lookup, slot index ---
+    CliqueTable ct;
+    uint64_t cumo[FCM_MAX_COUNTS] = {0};
+    s->clique_moves = cfg->move_weights[2] > 0.0 || cfg->move_weights[3] > 0.0;
+    if (s->clique_moves) {
+        if (!lossless) return fail(FCM_ERR_UNSUPPORTED, "clique moves need the lossless mode (dim_cap = 0)");
+        if ((rc = maximal_cliques(*g, und, ct))) return rc;
+        if (ct.orders > 15) return fail(FCM_ERR_UNSUPPORTED, "maximal cliques of %d vertices; the clique moves support up to 15", ct.orders);
+        // clique_order_distribution: weights (#cliques of the order)^0.2 (src/bin/sample.rs:87-88)
+        double tot = 0, acc = 0;
+        int last = 0;
+        for (int o = 0; o < ct.orders; ++o) {
+            const double wgt = std::pow((double)ct.count[o], 0.2);
+            tot += wgt;
+            if (wgt > 0.0) last = o;
+        }
+        for (int o = 0; o < ct.orders; ++o) {
+            acc += std::pow((double)ct.count[o], 0.2);
+            cumo[o] = (uint64_t)std::floor(4294967296.0 * (acc / tot));
+        }
+        for (int o = last; o < FCM_MAX_COUNTS; ++o) cumo[o] = 4294967296ull;
+        std::vector<uint32_t> efirst((size_t)g->n + 2, 0u);
+        for (uint64_t e = 0; e < U; ++e) efirst[etab[e].big + 1]++;
+        for (uint32_t v = 0; v < g->n; ++v) efirst[v + 1] += efirst[v];
+        if ((rc = s->d_clq.alloc((ct.flat.size() + 64) * sizeof(uint32_t)))) return rc;
+        if ((rc = s->d_efirst.alloc(efirst.size() * sizeof(uint32_t)))) return rc;
+        if ((rc = s->d_slot_of.alloc(std::max<size_t>(1, (size_t)C * U) * sizeof(uint32_t)))) return rc;
+        HIP_TRY(hipMemset(s->d_clq.p, 0, (ct.flat.size() + 64) * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(s->d_clq.p, ct.flat.data(), ct.flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_efirst.p, efirst.data(), efirst.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::vector<uint32_t> so((size_t)U, 0xFFFFFFFFu);
+        for (size_t j = 0; j < dbl0.size(); ++j) so[dbl0[j]] = (uint32_t)j;
+        for (uint32_t c = 0; c < C && U; ++c)
+            HIP_TRY(hipMemcpy(s->d_slot_of.as<uint32_t>() + (size_t)c * U, so.data(), (size_t)U * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipStreamCreate(&s->own_stream));
     s->stream = s->own_stream;
     HIP_TRY(hipEventCreate(&s->ev0));
@@ -697,6 +840,15 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     move_thresholds(cfg->move_weights, cum);
     p.cum0 = cum[0];
     p.cum1 = cum[1];
+    p.cum2 = cum[2];
+    if (s->clique_moves) {
+        p.clq = s->d_clq.as<uint32_t>();
+        p.efirst = s->d_efirst.as<uint32_t>();
+        p.slot_of = s->d_slot_of.as<uint32_t>();
+        for (int o = 0; o < FCM_MAX_COUNTS; ++o) { p.cl_base[o] = ct.base[o]; p.cl_count[o] = ct.count[o]; p.cumo[o] = cumo[o]; }
+        p.cl_orders = ct.orders;
+        p.chg_cap = (uint32_t)std::max(16, 2 * ct.orders * ct.orders);
+    }
     p.seed = cfg->seed;
     p.rows_per_chain = rows_per_chain;
     p.n = g->n;
@@ -718,8 +870,8 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     I.n_double = D;
     I.k_max = kmax;
     I.k_mean = U ? (double)ksum / (double)U : 0.0;
-    I.bytes_per_chain = rows_per_chain * 4 + (uint64_t)dbl_stride * 4 + FCM_MAX_COUNTS * 8 + FCM_NSTATS * 8;
-    I.bytes_static = etab.size() * sizeof(FcmEdgeEntry) + nb.size() * 4;
+    I.bytes_per_chain = rows_per_chain * 4 + (uint64_t)dbl_stride * 4 + FCM_MAX_COUNTS * 8 + FCM_NSTATS * 8 + (s->clique_moves ? U * 4 : 0);
+    I.bytes_static = etab.size() * sizeof(FcmEdgeEntry) + nb.size() * 4 + ct.flat.size() * 4;
     I.ncounts = nc;
     I.lossless = lossless ? 1 : 0;
     I.n_chains = C;
@@ -754,7 +906,7 @@ extern "C" int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals)
     while (left > 0) {
         const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
         s->params.nprop = chunk;
-        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->stream);
+        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? 1 : 0, s->stream);
         if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
         left -= chunk;
     }
@@ -922,7 +1074,7 @@ extern "C" int fcm_sampler_get_bounds(const fcm_sampler *s, fcm_bounds *out)
 // ---------------------------------------------------------------------------
 // Checkpoint / resume (role of src/io.rs:51-62)
 // ---------------------------------------------------------------------------
-static const char FCM_STATE_MAGIC[8] = {'F', 'C', 'M', 'S', 'T', 'A', 'T', '1'};
+static const char FCM_STATE_MAGIC[8] = {'F', 'C', 'M', 'S', 'T', 'A', 'T', '2'};
 
 struct StateHeader {
     char magic[8];
@@ -1027,6 +1179,14 @@ extern "C" int fcm_sampler_load_state(const char *path, int device, fcm_sampler 
         if (nd != D) return fail(FCM_ERR_IO, "%s: chain %u has %llu reciprocal pairs, header says %llu", path, c,
                                  (unsigned long long)nd, (unsigned long long)D);
         if (D) HIP_TRY(hipMemcpy(s->d_dbl.as<uint32_t>() + (size_t)c * s->params.dbl_stride, dbl.data(), (size_t)D * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (s->clique_moves && U) {   // inverse of the slot list
+            std::vector<uint32_t> so((size_t)U, 0xFFFFFFFFu);
+            for (uint64_t j = 0; j < D; ++j) {
+                if (dbl[j] >= U) return fail(FCM_ERR_IO, "%s: corrupt slot list", path);
+                so[dbl[j]] = (uint32_t)j;
+            }
+            HIP_TRY(hipMemcpy(s->d_slot_of.as<uint32_t>() + (size_t)c * U, so.data(), (size_t)U * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
     }
     HIP_TRY(hipMemcpy(s->d_counts.p, hc.data(), hc.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_stats.p, hs.data(), hs.size() * sizeof(uint64_t), hipMemcpyHostToDevice));

@@ -610,11 +610,15 @@ __device__ __forceinline__ void wide_add(const Wide W, const u32 *rows, u32 stri
     wide_dfs<false>(W, tmax, +1, nullptr);
 }
 
+#include "fcm_clique.hpp"
+
 // ===========================================================================
 // Step kernel
 // ===========================================================================
 // MINW = minimum waves per SIMD the register allocator must leave room for.
-template <int MAXT, int MINW>
+// CLIQUE = true adds the clique moves (fcm_clique.hpp); the simple-move kernel
+// is compiled without them and keeps its register allocation.
+template <int MAXT, int MINW, bool CLIQUE>
 __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];  // fcm_lds_words(p.maxnw) words
@@ -638,6 +642,8 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     const u64 bmax = cl ? p.bmax[lane] : ~0ull;
 
     u64 sampled = st_g[0], accepted = st_g[1], n_empty = st_g[2], n_flip = st_g[3], n_dmove = st_g[4], sum_k = st_g[5];
+    u64 n_cperm = st_g[8], n_cswap = st_g[9], n_changes = st_g[10];
+    u32 *slot_of = CLIQUE ? p.slot_of + (size_t)chain * p.U : nullptr;
     u32 count_len = (u32)st_g[6];
     u32 status = (u32)st_g[7];
 
@@ -657,10 +663,10 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         const u64 t = sampled + (u64)lane;
         u32 w[4];
         philox4x32_10((u32)t, (u32)(t >> 32), gchain, 0u, k0, k1, w);
-        const int l_move = ((u64)w[0] < p.cum0) ? 0 : (((u64)w[0] < p.cum1) ? 1 : 2);
-        const u32 l_coin = w[1] & 1u;
+        const int l_move = ((u64)w[0] < p.cum0) ? 0 : (((u64)w[0] < p.cum1) ? 1 : (((u64)w[0] < p.cum2) ? 2 : 3));
+        const u32 l_coin = w[1];  // coin = bit 0; the clique moves use the whole word for the order pick
         const u64 x64 = (u64)w[2] | ((u64)w[3] << 32);
-        const u64 l_idx = __umul64hi(x64, l_move == 0 ? Mtot : (u64)D);
+        const u64 l_idx = l_move >= 2 ? x64 : __umul64hi(x64, l_move == 0 ? Mtot : (u64)D);
         FcmEdgeEntry l_e = {0u, 0u, 0u, 0u};
         if (l_move == 0 && l_idx < U) l_e = p.etab[l_idx];
         // double-edge moves: the first two single-edge candidates (block sub=1)
@@ -676,7 +682,8 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         const int nbatch = (int)min((u64)WAVE, p.nprop - done);
         for (int sidx = 0; sidx < nbatch; ++sidx) {
             const int move = (int)rdlane((u32)l_move, sidx);
-            const u32 coin = rdlane(l_coin, sidx);
+            const u32 w1 = rdlane(l_coin, sidx);
+            const u32 coin = w1 & 1u;
             const u64 idx = rdlane64(l_idx, sidx);
 
             int delta[MAXT + 1];
@@ -688,6 +695,8 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             u32 c_clr_from = 0, c_clr_to = 0, c_set_from = 0, c_set_to = 0;
             u32 c_slot = 0, c_newdbl = 0;
             bool is_dmove = false;
+            int clq_nchg = 0, clq_nd = 0;
+            long long wide_d = 0;
 
             if (move == 0) {
                 // ---- single_edge_flip (src/lib.rs:292-299) -----------------
@@ -795,7 +804,21 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     }
                 }
             } else {
-                status |= 4u;  // clique moves are not built
+                // ---- clique_permute / clique_swap (src/lib.rs:214-290) -------
+                if constexpr (CLIQUE) {
+                    const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
+                    const CliqueResult cr = clique_propose<MAXT>(p, rows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta);
+                    status |= cr.status;
+                    if (cr.nchg > 0) {
+                        nonempty = true;
+                        clq_nchg = cr.nchg; clq_nd = cr.n_d;
+                        wide_d = cr.wide_d;
+                        sum_k += cr.sum_k;
+                        n_changes += (u64)cr.nchg;
+                    }
+                } else {
+                    status |= 4u;  // this kernel variant was built without the clique moves
+                }
             }
 
             // ---- sampled += 1; Bounds::check; accept or drop ---------------
@@ -804,7 +827,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 n_empty += 1;
                 if (in_bounds) accepted += 1;
             } else {
-                if (is_dmove) n_dmove += 1; else n_flip += 1;
+                if (move == 2) n_cperm += 1; else if (move == 3) n_cswap += 1; else if (is_dmove) n_dmove += 1; else n_flip += 1;
                 long long myd = 0;
                 if (used_wide) {
                     const Wide W = wide_carve(smem, maxnw);
@@ -819,6 +842,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         }
                     }
                 }
+                myd += wide_d;  // clique moves: evaluations that went through the wide path
                 const u64 ncnt = cnt + (u64)myd;
                 if (ballot(cl && myd < 0 && cnt < (u64)(-myd))) status |= 8u;  // reference assert, src/lib.rs:65
                 // flag_count never shrinks in length (src/lib.rs:72-74)
@@ -830,14 +854,32 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     accepted += 1;
                     in_bounds = true;
                     cnt = ncnt;
-                    if (lane == 0) {
-                        u32 *pc = rows + (size_t)c_clr_from * stride32 + (c_clr_to >> 5);
-                        *pc &= ~(1u << (c_clr_to & 31u));
-                        u32 *ps = rows + (size_t)c_set_from * stride32 + (c_set_to >> 5);
-                        *ps |= (1u << (c_set_to & 31u));
-                        if (is_dmove) dbl[c_slot] = c_newdbl;
+                    if (move >= 2) {
+                        if constexpr (CLIQUE) {  // bits are already in place; hand over the reciprocal-pair slots
+                            const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
+                            status |= clique_update_slots(p, dbl, slot_of, CL, clq_nd, lane);
+                        }
+                    } else {
+                        if (lane == 0) {
+                            u32 *pc = rows + (size_t)c_clr_from * stride32 + (c_clr_to >> 5);
+                            *pc &= ~(1u << (c_clr_to & 31u));
+                            u32 *ps = rows + (size_t)c_set_from * stride32 + (c_set_to >> 5);
+                            *ps |= (1u << (c_set_to & 31u));
+                            if (is_dmove) {
+                                if constexpr (CLIQUE) {
+                                    slot_of[dbl[c_slot]] = FCM_NOSLOT;
+                                    slot_of[c_newdbl] = c_slot;
+                                }
+                                dbl[c_slot] = c_newdbl;
+                            }
+                        }
+                        wave_sync();
                     }
-                    wave_sync();
+                } else if (move >= 2) {
+                    if constexpr (CLIQUE) {
+                        const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
+                        clique_revert(rows, stride32, CL, clq_nchg, lane);
+                    }
                 }
             }
         }
@@ -847,5 +889,6 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     if (lane == 0) {
         st_g[0] = sampled; st_g[1] = accepted; st_g[2] = n_empty; st_g[3] = n_flip;
         st_g[4] = n_dmove; st_g[5] = sum_k; st_g[6] = count_len; st_g[7] = status;
+        st_g[8] = n_cperm; st_g[9] = n_cswap; st_g[10] = n_changes;
     }
 }

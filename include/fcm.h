@@ -141,8 +141,7 @@ typedef struct {
     uint32_t n_chains;        /* chains held by this handle */
     uint32_t first_chain_id;  /* global id of chain 0: RNG stream = (seed, first_chain_id + i) */
     uint64_t seed;            /* `--seed` (src/bin/sample.rs:43-45) */
-    double move_weights[4];   /* [flip, double-move, clique_permute, clique_swap] (sample.rs:16-17);
-                                 entries 2,3 must be 0 in this build */
+    double move_weights[4];   /* [flip, double-move, clique_permute, clique_swap] (sample.rs:16-17) */
     uint64_t sample_distance; /* proposals per next(); 0 = default (sample.rs:102) */
     int32_t dim_cap;          /* 0 = lossless (track every reachable dimension); d>0 = track
                                  dimensions 0..d only ("truncated") */
@@ -179,7 +178,7 @@ uint64_t fcm_sampler_sample_distance(const fcm_sampler *s);
 int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 
 /* Per-chain counters, out[n_chains][FCM_NSTATS]. */
-#define FCM_NSTATS 8
+#define FCM_NSTATS 12
 #define FCM_STAT_SAMPLED 0    /* MCMCSampler::sampled (src/lib.rs:176) */
 #define FCM_STAT_ACCEPTED 1   /* MCMCSampler::accepted (src/lib.rs:177) */
 #define FCM_STAT_EMPTY 2      /* proposals whose transition was empty */
@@ -188,6 +187,9 @@ int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 #define FCM_STAT_SUM_K 5      /* sum over evaluated edges of |N(a) cap N(b)| */
 #define FCM_STAT_COUNT_LEN 6
 #define FCM_STAT_STATUS 7     /* 0 ok; non-zero = device-side check failed */
+#define FCM_STAT_CPERM 8      /* non-empty clique_permute proposals */
+#define FCM_STAT_CSWAP 9      /* non-empty clique_swap proposals */
+#define FCM_STAT_CHANGES 10   /* directed edges changed by clique-move proposals */
 int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out);
 
 /* Directed edge list of one chain's current graph, ascending (from,to). */

@@ -43,7 +43,7 @@ def compare_chain(fcm_sampler, chain_idx, ochain, ctx=""):
     """Exact comparison of one GPU chain with its oracle twin (tolerance 0)."""
     ost = ochain.stats()
     gst = fcm_sampler.stats()
-    for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k"):
+    for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes"):
         assert int(gst[k][chain_idx]) == ost[k], (ctx, k, int(gst[k][chain_idx]), ost[k])
     assert fcm_sampler.flag_count(chain_idx) == ochain.state.flag_count, ctx
     ge = fcm_sampler.edges(chain_idx)

@@ -233,9 +233,6 @@ def test_unsupported_inputs_fail_loudly(fcm):
     from flag_complex_mcmc_amd import graphs
     g = fcm.Graph.from_edges(4, graphs.simplex(3))
     b = fcm.Bounds([4, 6, 0, 0], [4, 6, 9, 9])
-    with pytest.raises(fcm.FcmError) as ei:
-        fcm.MCMCSampler(g, b, move_weights=fcm.MOVE_DISTRIBUTION)     # clique moves: SURVEY.md 8f
-    assert ei.value.code == 4
     with pytest.raises(fcm.FcmError):
         fcm.MCMCSampler(g, b, move_weights=(0, 0, 0, 0))
     # more reachable dimensions than the 16 tracked count entries
@@ -485,7 +482,59 @@ def test_sample_cli_matches_library_and_resumes(fcm, golden_dir, tmp_path):
     assert "flag count: %s" % s.flag_count(0) in r2.stdout
     n, resumed = fcm.MCMCSampler.load_state(str(state))
     assert n == 5 and (resumed.flag_counts() == s.flag_counts()).all()
-    # without --simple the CLI refuses (clique moves are not built)
-    r3 = subprocess.run([exe, "-i", flag, "-l", "x", "--samples-store-dir", str(tmp_path / "s3"), "--state-store-dir", str(stdir)],
-                        capture_output=True, text=True, timeout=300)
-    assert r3.returncode != 0 and "simple" in r3.stderr
+
+
+# ----------------------------------- clique moves (src/lib.rs:214-290)
+CLIQUE_WEIGHTS = [(0.0, 0.0, 1.0, 0.0), (0.0, 0.0, 0.0, 1.0), (0.1, 0.1, 0.6, 0.2)]
+
+
+@pytest.mark.parametrize("weights", CLIQUE_WEIGHTS)
+def test_clique_moves_trajectory_parity(fcm, oracle, weights):
+    from flag_complex_mcmc_amd import graphs
+    # dense small graph: big cliques, many reciprocal pairs, overlapping cliques for clique_swap
+    e = graphs.random_with_p(40, 0.35, seed=1)
+    s, tw = _run_parity(fcm, oracle, 40, e, n_chains=3, steps=[1, 1, 1, 61, 200], seed=4, weights=weights, relaxation=0.2)
+    st = s.stats()
+    if weights[2] > 0:
+        assert (st["n_cperm"] > 0).all()
+    if weights[3] > 0:
+        assert (st["n_cswap"] > 0).all()
+    assert (st["n_changes"] > 0).all() and (st["accepted"] < st["sampled"]).any()
+    # sparser, larger: cliques of order 3-5
+    e = graphs.random_with_p(150, 0.12, seed=2)
+    _run_parity(fcm, oracle, 150, e, n_chains=2, steps=[300], seed=5, weights=weights)
+
+
+def test_clique_moves_on_fixture_and_invariants(fcm, oracle):
+    n, e = load_flag_fixture("bug_calc_relax_de.flag")
+    s, tw = _run_parity(fcm, oracle, n, e, n_chains=2, steps=[400], seed=6, weights=(0.1, 0.1, 0.6, 0.2))
+    und0 = fcm.Graph.from_edges(n, e).undirected_edges()
+    for c in range(2):
+        g = s.graph(c)
+        fc = s.flag_count(c)
+        while fc[-1] == 0:
+            fc.pop()
+        assert g.flagser_count() == fc and (g.undirected_edges() == und0).all() and g.nedges() == len(e)
+
+
+def test_default_mix_config3_invariants(fcm):
+    """The reference's default move mix [0.1,0.1,0.6,0.2] (src/bin/sample.rs:17) on
+    the config-3 graph, 64 chains: size-independent checks."""
+    from flag_complex_mcmc_amd import graphs
+    n = 1000
+    e = graphs.random_with_p(n, 0.10, 0)
+    s = fcm.initialize_new_sampler(fcm.Graph.from_edges(n, e), n_chains=64, seed=0, simple=False)
+    s.step(300)
+    st = s.stats()
+    assert (st["sampled"] == 300).all()
+    assert (st["n_empty"] + st["n_flip"] + st["n_dmove"] + st["n_cperm"] + st["n_cswap"] == 300).all()
+    assert (st["n_cperm"] > 100).all() and (st["n_cswap"] > 20).all()
+    und0 = fcm.Graph.from_edges(n, e).undirected_edges()
+    for c in (0, 63):
+        g = s.graph(c)
+        fc = s.flag_count(c)
+        while fc[-1] == 0:
+            fc.pop()
+        assert g.flagser_count() == fc
+        assert (g.undirected_edges() == und0).all() and g.nedges() == len(e)
+        assert s.bounds.check(s.flag_count(c))
