@@ -28,8 +28,9 @@ def algorithmic_bytes(d, n):
     (k+4) rows + 64 B of word updates, double-edge move (k1+k2+8) rows + 128 B,
     an empty proposal 16 B."""
     W = 8 * ((n + 63) // 64)
-    return (int(d["sum_k"]) + 4 * int(d["n_flip"]) + 8 * int(d["n_dmove"])) * W \
-        + 64 * int(d["n_flip"]) + 128 * int(d["n_dmove"]) + 16 * int(d["n_empty"])
+    nchg = int(d.get("n_changes", 0))  # clique moves: every changed directed edge is one (k+2)-row evaluation
+    return (int(d["sum_k"]) + 4 * int(d["n_flip"]) + 8 * int(d["n_dmove"]) + 2 * nchg) * W \
+        + 64 * int(d["n_flip"]) + 128 * int(d["n_dmove"]) + 64 * nchg + 16 * int(d["n_empty"])
 
 
 def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
@@ -88,6 +89,8 @@ def main():
     ap.add_argument("--p", type=float, default=0.10)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--moves", choices=["simple", "default"], default="simple",
+                    help="simple = [0.5,0.5,0,0] (the headline path); default = the reference's [0.1,0.1,0.6,0.2] with clique moves")
     args = ap.parse_args()
 
     import numpy as np
@@ -119,7 +122,8 @@ def main():
     bounds = fcm.Bounds.calculate(g, flag_count, fcm.Bounds.target(flag_count, 0.01), device=local_rank)
     total_chains = args.chains * world                      # weak scaling: fixed chains per GPU
     lo, hi = fdist.shard_range(total_chains, rank, world)
-    s = fcm.MCMCSampler(g, bounds, n_chains=hi - lo, seed=args.seed, move_weights=fcm.MOVE_DISTRIBUTION_SIMPLE,
+    weights = fcm.MOVE_DISTRIBUTION_SIMPLE if args.moves == "simple" else fcm.MOVE_DISTRIBUTION
+    s = fcm.MCMCSampler(g, bounds, n_chains=hi - lo, seed=args.seed, move_weights=weights,
                         device=local_rank, first_chain_id=lo)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -163,7 +167,7 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- parity gate on this rank's result (outside the timed region) ----------
-    d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k")}
+    d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes")}
     assert d["sampled"] == (hi - lo) * args.steps * args.proposals, "proposal count mismatch"
     def strip(v):  # flag_count never shrinks in length (src/lib.rs:72-74): ignore trailing zeros
         v = list(v)
@@ -185,15 +189,17 @@ def main():
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32/u64 bitset", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: Erdos-Renyi digraph n=%d p=%.2f seed %d, %d chains per GPU, "
-                                   "%d proposals per chain per step, --simple moves [0.5,0.5,0,0], target_relaxation 0.01"
-                                   % (args.n, args.p, args.seed, args.chains, args.proposals),
+                                   "%d proposals per chain per step, moves %s, target_relaxation 0.01"
+                                   % (args.n, args.p, args.seed, args.chains, args.proposals, list(weights)),
                        "n": args.n, "p": args.p, "chains_per_gpu": args.chains, "proposals_per_step": args.proposals,
                        "edges": int(len(edges)), "initial_flag_count": flag_count, "parallelism": "chains sharded, %d rank(s)" % world},
             "per_gpu_value": total_prop / elapsed / world,
             "kernel_ms_per_launch": kernel_ms,
             "accept_ratio": float(d["accepted"]) / float(d["sampled"]),
             "empty_fraction": float(d["n_empty"]) / float(d["sampled"]),
-            "mean_k": float(d["sum_k"]) / max(1.0, float(d["n_flip"] + 2 * d["n_dmove"])),
+            "mean_k": float(d["sum_k"]) / max(1.0, float(d["n_flip"] + 2 * d["n_dmove"] + d["n_changes"])),
+            "clique_move_fraction": float(d["n_cperm"] + d["n_cswap"]) / float(d["sampled"]),
+            "changed_edges_per_clique_move": float(d["n_changes"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"])),
             "count_histogram_dim2_distinct": int(len(fdist.count_histogram(all_counts, 2)[0])),
             "parity": "counts == full GPU recount on 3 chains; oracle parity in tests/ -m gpu",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

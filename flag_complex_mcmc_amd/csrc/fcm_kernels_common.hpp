@@ -737,16 +737,11 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     // probability ~0.99, so the later blocks are almost never computed.
                     const u64 tt = sampled;  // this proposal's step index
                     const u64 c0 = rdlane64(l_c0, sidx), c1 = rdlane64(l_c1, sidx);
-                    u64 rr = lane == 0 ? c0 : c1;
                     FcmEdgeEntry ce = {0u, 0u, 0u, 0u};
                     u32 fwd = 0;
-                    u64 vm = 0ull;
-                    for (int base = 0; base < WAVE && vm == 0ull; base += 2) {
-                        if (base > 0) {  // rare: draw block sub = base/2 + 1 now
-                            u32 v[4];
-                            philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(base >> 1) + 1u, k0, k1, v);
-                            rr = __umul64hi((lane & 1) ? ((u64)v[2] | ((u64)v[3] << 32)) : ((u64)v[0] | ((u64)v[1] << 32)), Mtot);
-                        }
+                    u64 rr = lane == 0 ? c0 : c1;
+                    // probe two candidates (lanes 0, 1): valid = names an adjacent pair that is not reciprocal
+                    auto probe = [&]() -> u64 {
                         bool valid = lane < 2 && rr < U;
                         if (valid) {
                             ce = p.etab[rr];
@@ -756,7 +751,18 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             const u32 bwd = (wb >> (ce.big & 31u)) & 1u;
                             valid = (fwd ^ bwd) != 0u;
                         }
-                        vm = ballot(valid);
+                        return ballot(valid);
+                    };
+                    u64 vm = probe();
+                    if (__builtin_expect(vm == 0ull, 0)) {
+                        // rare (~1 %): draw the later blocks sub = 2.. only now
+#pragma nounroll
+                        for (int base = 2; base < WAVE && vm == 0ull; base += 2) {
+                            u32 v[4];
+                            philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(base >> 1) + 1u, k0, k1, v);
+                            rr = __umul64hi((lane & 1) ? ((u64)v[2] | ((u64)v[3] << 32)) : ((u64)v[0] | ((u64)v[1] << 32)), Mtot);
+                            vm = probe();
+                        }
                     }
                     if (vm) {
                         const int first = __ffsll((long long)vm) - 1;

@@ -247,6 +247,6 @@ private:
 }  // namespace io
 
 static const double MOVE_DISTRIBUTION_SIMPLE[4] = {0.5, 0.5, 0.0, 0.0};  // src/bin/sample.rs:16
-static const double MOVE_DISTRIBUTION[4] = {0.1, 0.1, 0.6, 0.2};         // src/bin/sample.rs:17 (clique moves not built)
+static const double MOVE_DISTRIBUTION[4] = {0.1, 0.1, 0.6, 0.2};         // src/bin/sample.rs:17
 
 }  // namespace fcm

@@ -4,7 +4,7 @@
 // Same options as the reference's clap Args (src/bin/sample.rs:21-78) where
 // they apply, plus --chains / --device / --dim-cap.  Differences, all forced
 // by scope: samples are written as edgebits only (--save-bits is
-// implied; HDF5 is out of scope), and only the --simple move mix exists.
+// implied; HDF5 is out of scope).
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -33,7 +33,7 @@ static void usage()
             "  -s, --seed <seed> [0]           --sample-distance <d> [0 = 2 E log2 E]\n"
             "  -c, --continue-from <state>     --samples-store-dir <dir> [./samples/]\n"
             "  --state-store-dir <dir> [./state/]   --state-save-interval <k> [100]\n"
-            "  --simple (required: clique moves are not built)   --save-bits (implied)\n"
+            "  --simple   only single edge flips and double edge moves     --save-bits (implied)\n"
             "  --chains <n> [1]   --device <d> [0]   --dim-cap <d> [0 = lossless]\n");
 }
 
@@ -83,8 +83,9 @@ static fcm::MCMCSampler initialize_new_sampler(const Args &args)
     print_counts("  s(G): ", flag_count);
     print_counts("   s^+: ", target.flag_count_max);
     print_counts("  s^++: ", bounds.flag_count_max);
-    if (!args.simple) throw fcm::Error(FCM_ERR_UNSUPPORTED, "only --simple (single edge flips and double edge moves) is built");
-    fcm::MCMCSampler s(g, bounds, args.chains, args.seed, fcm::MOVE_DISTRIBUTION_SIMPLE, args.sample_distance, args.device, args.dim_cap);
+    // src/bin/sample.rs:101: --simple selects [0.5,0.5,0,0], the default is [0.1,0.1,0.6,0.2]
+    fcm::MCMCSampler s(g, bounds, args.chains, args.seed, args.simple ? fcm::MOVE_DISTRIBUTION_SIMPLE : fcm::MOVE_DISTRIBUTION,
+                       args.sample_distance, args.device, args.dim_cap);
     printf("The sampling distance was set to %zu.\n", s.sample_distance());
     return s;
 }

@@ -482,6 +482,19 @@ def test_sample_cli_matches_library_and_resumes(fcm, golden_dir, tmp_path):
     assert "flag count: %s" % s.flag_count(0) in r2.stdout
     n, resumed = fcm.MCMCSampler.load_state(str(state))
     assert n == 5 and (resumed.flag_counts() == s.flag_counts()).all()
+    # without --simple the CLI runs the reference's default mix with the clique moves (sample.rs:17,101)
+    r3 = subprocess.run([exe, "-i", flag, "-l", "dflt", "-s", "1", "-n", "2", "--chains", "2", "--sample-distance", "120",
+                         "--samples-store-dir", str(tmp_path / "s3"), "--state-store-dir", str(stdir)],
+                        capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    d = fcm.initialize_new_sampler(flag, seed=1, n_chains=2, sample_distance=120, simple=False)
+    d.next(); d.next()
+    assert (d.stats()["n_cperm"] > 0).all()
+    assert "flag count: %s" % d.flag_count(0) in r3.stdout
+    # ... and its state file resumes with the slot index rebuilt
+    n2, res2 = fcm.MCMCSampler.load_state(str(stdir / "sampler-dflt-001.state"))
+    res2.next(); d.next()
+    assert n2 == 2 and (res2.flag_counts() == d.flag_counts()).all() and (res2.edges(1) == d.edges(1)).all()
 
 
 # ----------------------------------- clique moves (src/lib.rs:214-290)

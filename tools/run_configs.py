@@ -36,7 +36,7 @@ def run(name, n, edges, chains, proposals, launches, dim_cap=0):
     s.sync()
     dt = time.perf_counter() - t1
     st1 = s.stats()
-    d = {k: int((st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum()) for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k")}
+    d = {k: int((st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum()) for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes")}
     ok = True
     for c in (0, chains - 1):
         full = s.graph(c).flagser_count()
