@@ -107,11 +107,21 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available() or fcm.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libfcm has no CPU path")
+    # Rehearsal on a 1-GPU box: FCM_BENCH_REHEARSE=1 lets all ranks share GPU 0 and talk over gloo
+    # (RCCL refuses two ranks on one device).  The driver's multi-GPU run uses one GPU per rank and RCCL.
+    rehearse = os.environ.get("FCM_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     # ---- workload: synthetic ER digraph, same on every rank ---------------------
     edges = fcm.graphs.random_with_p(args.n, args.p, args.seed)
@@ -159,10 +169,10 @@ def main():
     st1 = s.stats()
     counts = s.flag_counts()
     stat_mat = np.stack([st1[k] for k in fcm._ffi.STAT_NAMES], axis=1)
-    all_counts, all_stats = fdist.gather_counts(counts, stat_mat, device=dev)
+    all_counts, all_stats = fdist.gather_counts(counts, stat_mat, device=None if rehearse else dev)
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -202,6 +212,7 @@ def main():
             "changed_edges_per_clique_move": float(d["n_changes"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"])),
             "count_histogram_dim2_distinct": int(len(fdist.count_histogram(all_counts, 2)[0])),
             "parity": "counts == full GPU recount on 3 chains; oracle parity in tests/ -m gpu",
+            "gathered_chains": int(all_counts.shape[0]),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic(args.chains, args.proposals),
