@@ -281,7 +281,8 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
 }
 
 // ---- the three evaluations a simple move is made of (fast path) -------------
-// K then big, small: lane k = big, lane k+1 = small.  Hs = raw masks, Hp = split
+// Lv = the local vertex list (K, then big, small: lane k = big, lane k+1 = small),
+// loaded by the caller.  Hs = raw masks, Hp = split
 // graph (both 64 u64 in LDS).  Each returns FCM_NEEDS_WIDE when the extras do
 // not fit; the caller then zeroes delta and redoes the proposal on the wide path.
 
@@ -289,11 +290,10 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
 // reciprocal (empty transition), 1 if big->small was flipped, 2 if small->big,
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
-__device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
+__device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, u32 Lv, int k,
                                          u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
-    const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
     u64 myH = build_local(rows, stride32, Lv, s, lane);
     Hs[lane] = myH;
     wave_sync();
@@ -315,11 +315,10 @@ __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, const u3
 // reciprocal pair (big,small).  coin=1 removes big->small.  Returns 1, or 0 if
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
-__device__ __forceinline__ int del_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
+__device__ __forceinline__ int del_eval(const u32 *rows, u32 stride32, u32 Lv, int k,
                                         u32 coin, u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
-    const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
     const u64 myH = build_local(rows, stride32, Lv, s, lane);
     Hs[lane] = myH;
     wave_sync();
@@ -333,14 +332,13 @@ __device__ __forceinline__ int del_eval(const u32 *rows, u32 stride32, const u32
 
 // double_edge_move step 2: on the graph without dfrom->dto, add the reverse of
 // the single edge of (big,small) and add the simplices through it.  fwd=1
-// means big->small is the existing direction.
+// means big->small is the existing direction.  `myH` = the lane's raw mask of
+// the local set Lv (k vertices of K, then big, small), built by the caller.
 template <int MAXT>
-__device__ __forceinline__ int add_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                        u32 fwd, u32 dfrom, u32 dto, u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
+__device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u32 dfrom, u32 dto, u64 *Hs, u64 *Hp, int lane,
+                                              int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
-    const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
-    u64 myH = build_local(rows, stride32, Lv, s, lane);
     const bool act = lane < s;
     const u64 mf = ballot(act && Lv == dfrom), mt = ballot(act && Lv == dto);
     if (mf && mt) {  // the pending removal, if both its endpoints are local
@@ -355,6 +353,12 @@ __device__ __forceinline__ int add_eval(const u32 *rows, u32 stride32, const u32
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
     eval_nodes<MAXT>(myH, Hp, c, k, tmax, +1, lane, delta);
     return 1;
+}
+
+// local vertex list of an adjacent pair: K, then big, small
+__device__ __forceinline__ u32 load_list(const u32 *nb, u32 off, int k, u32 big, u32 small, int lane)
+{
+    return lane < k ? nb[off + lane] : (lane == k ? big : small);
 }
 
 // ===========================================================================
@@ -677,6 +681,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             philox4x32_10((u32)t, (u32)(t >> 32), gchain, 1u, k0, k1, v);
             l_c0 = __umul64hi((u64)v[0] | ((u64)v[1] << 32), Mtot);
             l_c1 = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
+            if (l_c0 < U) l_e = p.etab[l_c0];  // candidate 0 wins ~9 times in 10: have its table entry ready
         }
 
         const int nbatch = (int)min((u64)WAVE, p.nprop - done);
@@ -705,7 +710,10 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     const u32 off = rdlane(l_e.nb_off, sidx);
                     const int k = (int)rdlane(l_e.k, sidx);
                     int res = FCM_NEEDS_WIDE;
-                    if (k + 2 <= WAVE) res = flip_eval<MAXT>(rows, stride32, nb, off, k, a, b, Hs, Hp, lane, tmax, delta);
+                    if (k + 2 <= WAVE) {
+                        const u32 Lv = load_list(nb, off, k, a, b, lane);
+                        res = flip_eval<MAXT>(rows, stride32, Lv, k, Hs, Hp, lane, tmax, delta);
+                    }
                     if (res == FCM_NEEDS_WIDE) {
                         if (k + 2 <= 64 * maxnw) {
                             const Wide W = wide_carve(smem, maxnw);
@@ -733,44 +741,52 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     // Up to 64 candidate draws for the single edge (two per Philox block
                     // sub = 1..32), first valid in order wins (uniform directed edge, retry
                     // while reciprocal: :308-313).  Candidates 0 and 1 come from the batch
-                    // draw and are probed by lanes 0 and 1; one of them is valid with
-                    // probability ~0.99, so the later blocks are almost never computed.
+                    // draw.  Whether a candidate pair is single or reciprocal is read off the
+                    // masks of its own local build (bits k<->k+1): no separate probe of the
+                    // bitmap, and the build is the one step 2 needs anyway.
                     const u64 tt = sampled;  // this proposal's step index
-                    const u64 c0 = rdlane64(l_c0, sidx), c1 = rdlane64(l_c1, sidx);
-                    FcmEdgeEntry ce = {0u, 0u, 0u, 0u};
-                    u32 fwd = 0;
-                    u64 rr = lane == 0 ? c0 : c1;
-                    // probe two candidates (lanes 0, 1): valid = names an adjacent pair that is not reciprocal
-                    auto probe = [&]() -> u64 {
-                        bool valid = lane < 2 && rr < U;
-                        if (valid) {
-                            ce = p.etab[rr];
-                            const u32 wf = rows[(size_t)ce.big * stride32 + (ce.small >> 5)];
-                            const u32 wb = rows[(size_t)ce.small * stride32 + (ce.big >> 5)];
-                            fwd = (wf >> (ce.small & 31u)) & 1u;
-                            const u32 bwd = (wb >> (ce.big & 31u)) & 1u;
-                            valid = (fwd ^ bwd) != 0u;
-                        }
-                        return ballot(valid);
-                    };
-                    u64 vm = probe();
-                    if (__builtin_expect(vm == 0ull, 0)) {
-                        // rare (~1 %): draw the later blocks sub = 2.. only now
+                    u64 cand = rdlane64(l_c0, sidx);
+                    u64 cand_next = rdlane64(l_c1, sidx);
+                    FcmEdgeEntry ce;
+                    ce.big = rdlane(l_e.big, sidx); ce.small = rdlane(l_e.small, sidx);
+                    ce.nb_off = rdlane(l_e.nb_off, sidx); ce.k = rdlane(l_e.k, sidx);
+                    bool have_ce = true, found = false;
+                    u32 rfwd = 0u, Lv2 = 0u;
+                    u64 myH2 = 0ull;
 #pragma nounroll
-                        for (int base = 2; base < WAVE && vm == 0ull; base += 2) {
+                    for (int ci = 0; ci < WAVE && !found; ++ci) {
+                        if (ci >= 2 && (ci & 1) == 0) {  // rare: draw block sub = ci/2 + 1 now
                             u32 v[4];
-                            philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(base >> 1) + 1u, k0, k1, v);
-                            rr = __umul64hi((lane & 1) ? ((u64)v[2] | ((u64)v[3] << 32)) : ((u64)v[0] | ((u64)v[1] << 32)), Mtot);
-                            vm = probe();
+                            philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(ci >> 1) + 1u, k0, k1, v);
+                            cand = __umul64hi((u64)v[0] | ((u64)v[1] << 32), Mtot);
+                            cand_next = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
+                        } else if (ci >= 1) {
+                            cand = cand_next;
                         }
+                        if (cand < U) {
+                            if (!have_ce) ce = p.etab[cand];
+                            const int ck = (int)ce.k;
+                            if (ck + 2 <= WAVE) {
+                                Lv2 = load_list(nb, ce.nb_off, ck, ce.big, ce.small, lane);
+                                myH2 = build_local(rows, stride32, Lv2, ck + 2, lane);
+                                const u32 f = (u32)(rdlane64(myH2, ck) >> (ck + 1)) & 1u, bwd = (u32)(rdlane64(myH2, ck + 1) >> ck) & 1u;
+                                if (!(f | bwd)) status |= 1u;
+                                found = (f ^ bwd) != 0u;
+                                rfwd = f;
+                            } else {  // wide candidate: look at its two words directly
+                                const u32 wf = rows[(size_t)ce.big * stride32 + (ce.small >> 5)];
+                                const u32 wb = rows[(size_t)ce.small * stride32 + (ce.big >> 5)];
+                                const u32 f = (wf >> (ce.small & 31u)) & 1u, bwd = (wb >> (ce.big & 31u)) & 1u;
+                                found = (f ^ bwd) != 0u;
+                                rfwd = f;
+                            }
+                        }
+                        have_ce = false;
                     }
-                    if (vm) {
-                        const int first = __ffsll((long long)vm) - 1;
-                        const u32 r = (u32)rdlane64(rr, first);
-                        const u32 rbig = rdlane(ce.big, first), rsmall = rdlane(ce.small, first);
-                        const u32 roff = rdlane(ce.nb_off, first);
-                        const int rk = (int)rdlane(ce.k, first);
-                        const u32 rfwd = rdlane(fwd, first);
+                    if (found) {
+                        const u32 r = (u32)cand;
+                        const u32 rbig = ce.big, rsmall = ce.small, roff = ce.nb_off;
+                        const int rk = (int)ce.k;
                         const u32 ea = rfwd ? rbig : rsmall, eb = rfwd ? rsmall : rbig;  // ea->eb is the single edge
                         // delme: coin ? (big->small) : (small->big) of the reciprocal pair (:316-320)
                         const u32 dfrom = coin ? de.big : de.small, dto = coin ? de.small : de.big;
@@ -780,12 +796,13 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         bool okd = true;
                         if (!go_wide) {
                             // (1) remove delme: subtract simplices through it
-                            const int r1 = del_eval<MAXT>(rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, Hs, Hp, lane, tmax, delta);
+                            const u32 Lv1 = load_list(nb, de.nb_off, dk, de.big, de.small, lane);
+                            const int r1 = del_eval<MAXT>(rows, stride32, Lv1, dk, coin, Hs, Hp, lane, tmax, delta);
                             go_wide = r1 == FCM_NEEDS_WIDE;
                             okd = r1 != 0;
                             if (!go_wide) {
                                 // (2) add eb->ea on the graph without delme: add simplices through it
-                                const int r2 = add_eval<MAXT>(rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, Hs, Hp, lane, tmax, delta);
+                                const int r2 = add_eval_built<MAXT>(myH2, Lv2, rk, rfwd, dfrom, dto, Hs, Hp, lane, tmax, delta);
                                 go_wide = r2 == FCM_NEEDS_WIDE;
                             }
                         }
