@@ -40,7 +40,7 @@ __device__ __forceinline__ CliqueLds clique_carve(u64 *base)
 
 // one evaluation of an edge present in the bitmap: fast path, FCM_NEEDS_WIDE if it does not fit
 template <int MAXT>
-__device__ __forceinline__ int edge_eval(const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
+__device__ __forceinline__ int edge_eval(const rsrc_t rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
                                          u32 fwd, int sign, u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
@@ -97,7 +97,7 @@ struct CliqueResult {
 // the simplex-count change to `delta` (fast evaluations) and res.wide_d (wide).
 // move == 2: clique_permute, 3: clique_swap.
 template <int MAXT>
-__device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, u64 *smem, const CliqueLds CL, int move,
+__device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, const rsrc_t rrows, u64 *smem, const CliqueLds CL, int move,
                                                        u32 w1, u64 x64, u64 step, u32 gchain, u32 k0, u32 k1, int lane, int tmax,
                                                        int maxnw, int (&delta)[MAXT + 1])
 {
@@ -235,7 +235,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
             wave_sync();
         }
         int r = FCM_NEEDS_WIDE;
-        if (k + 2 <= WAVE) r = edge_eval<MAXT>(rows, stride32, p.nb, de.nb_off, k, big, small, fwd, add ? +1 : -1, Hs, Hp, lane, tmax, delta);
+        if (k + 2 <= WAVE) r = edge_eval<MAXT>(rrows, stride32, p.nb, de.nb_off, k, big, small, fwd, add ? +1 : -1, Hs, Hp, lane, tmax, delta);
         if (r == FCM_NEEDS_WIDE) {
             if (k + 2 <= 64 * maxnw) {
                 const Wide W = wide_carve(smem, maxnw);

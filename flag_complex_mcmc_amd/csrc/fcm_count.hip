@@ -19,6 +19,7 @@ __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
     u32 *Lc = W.L;       // candidate list, both paths
     const int lane = threadIdx.x;
     const u32 nwords = (p.n + 31u) >> 5;
+    const rsrc_t rrows = make_rows_rsrc(p.rows, (u64)p.n * p.stride32 * 4ull);
     u64 acc[FCM_COUNT_MAXT + 1];
 #pragma unroll
     for (int q = 0; q <= FCM_COUNT_MAXT; ++q) acc[q] = 0ull;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
         wave_sync();
         if (total <= WAVE) {
             const u32 Lv = lane < (int)total ? Lc[lane] : 0u;
-            const u64 myH = build_local(p.rows, p.stride32, Lv, (int)total, lane);
+            const u64 myH = build_local(rrows, p.stride32, Lv, (int)total, lane);
             wave_sync();
             Hs[lane] = myH;
             wave_sync();

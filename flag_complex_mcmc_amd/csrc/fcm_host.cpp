@@ -90,6 +90,7 @@ struct fcm_graph {
     }
 };
 
+static uint32_t stride_for(uint32_t n);
 static uint32_t stride_for(uint32_t n)
 {
     uint32_t w = (n + 31) / 32;
@@ -100,6 +101,9 @@ static uint32_t stride_for(uint32_t n)
 extern "C" int fcm_graph_new_disconnected(uint32_t nnodes, fcm_graph **out)
 {
     if (!out) return fail(FCM_ERR_INVALID, "out is NULL");
+    // the kernels address one bitmap through a buffer descriptor with 32-bit byte offsets
+    if ((uint64_t)nnodes * stride_for(nnodes) * 4ull >= (1ull << 32))
+        return fail(FCM_ERR_UNSUPPORTED, "%u vertices: the row bitmap would exceed 4 GiB", nnodes);
     fcm_graph *g = new (std::nothrow) fcm_graph;
     if (!g) return fail(FCM_ERR_NOMEM, "out of memory");
     g->n = nnodes;

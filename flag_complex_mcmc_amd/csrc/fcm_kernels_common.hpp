@@ -123,45 +123,47 @@ __device__ __forceinline__ void wave_sync()
 #ifndef FCM_HB
 #define FCM_HB 24  // rows in flight per batch (16: -2%, 32: -4% on config 3)
 #endif
-__device__ __forceinline__ u64 build_local(const u32 *rows, u32 stride32, u32 Lv, int s, int lane)
+// Buffer descriptor over one chain's bitmap (or the counter's graph): raw
+// buffer, 32-bit offsets, out-of-range reads return 0.  `bytes` < 4 GiB is
+// checked on the host.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rows_rsrc(const u32 *rows, u64 bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)rows, 0, (int)(u32)bytes, 0x00020000);
+}
+// lane `l` of (lo, hi) := the wave-uniform 64-bit value m; one m0 write for both halves
+__device__ __forceinline__ void wrlane64(u64 m, int l, u32 &lo, u32 &hi)
+{
+    asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                 : "+v"(lo), "+v"(hi) : "s"((u32)m), "s"((u32)(m >> 32)), "s"(l) : "m0");
+}
+
+__device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 Lv, int s, int lane)
 {
     const bool act = lane < s;
-    const u32 woff = act ? (Lv >> 5) : 0u;
-    const u32 bmask = act ? (1u << (Lv & 31u)) : 0u;  // inactive lanes never set a bit
+    const u32 voff = act ? (Lv >> 5) * 4u : 0u;          // byte offset of this lane's dword inside a row
+    const u32 bmask = act ? (1u << (Lv & 31u)) : 0u;     // inactive lanes never set a bit
+    const u32 roff = Lv * (stride32 * 4u);               // byte offset of row Lv; read back per row by v_readlane
     u32 hlo = 0u, hhi = 0u;                              // this lane's row, written by v_writelane
     int i0 = 0;
     for (; i0 + FCM_HB <= s; i0 += FCM_HB) {             // full batches: FCM_HB row reads in flight
         u32 w[FCM_HB];
 #pragma unroll
-        for (int q = 0; q < FCM_HB; ++q) {
-            const u32 *row = rows + (size_t)rdlane(Lv, i0 + q) * stride32;  // scalar base + per-lane dword offset
-            w[q] = row[woff];
-        }
+        for (int q = 0; q < FCM_HB; ++q)                 // buffer_load_dword v, voff, rsrc, soffset: no address arithmetic
+            w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
 #pragma unroll
-        for (int q = 0; q < FCM_HB; ++q) {
-            const u64 m = ballot((w[q] & bmask) != 0u);
-            hlo = wrlane((u32)m, i0 + q, hlo);
-            hhi = wrlane((u32)(m >> 32), i0 + q, hhi);
-        }
+        for (int q = 0; q < FCM_HB; ++q) wrlane64(ballot((w[q] & bmask) != 0u), i0 + q, hlo, hhi);
     }
     if (i0 < s) {                                        // last, partial batch: only the rows that exist
         u32 w[FCM_HB];
 #pragma unroll
         for (int q = 0; q < FCM_HB; ++q) {
             w[q] = 0u;
-            if (i0 + q < s) {
-                const u32 *row = rows + (size_t)rdlane(Lv, i0 + q) * stride32;
-                w[q] = row[woff];
-            }
+            if (i0 + q < s) w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
         }
 #pragma unroll
-        for (int q = 0; q < FCM_HB; ++q) {
-            if (i0 + q < s) {
-                const u64 m = ballot((w[q] & bmask) != 0u);
-                hlo = wrlane((u32)m, i0 + q, hlo);
-                hhi = wrlane((u32)(m >> 32), i0 + q, hhi);
-            }
-        }
+        for (int q = 0; q < FCM_HB; ++q)
+            if (i0 + q < s) wrlane64(ballot((w[q] & bmask) != 0u), i0 + q, hlo, hhi);
     }
     return (u64)hlo | ((u64)hhi << 32);  // lanes >= s were never written: 0
 }
@@ -290,7 +292,7 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
 // reciprocal (empty transition), 1 if big->small was flipped, 2 if small->big,
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
-__device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, u32 Lv, int k,
+__device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
                                          u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
@@ -315,7 +317,7 @@ __device__ __forceinline__ int flip_eval(const u32 *rows, u32 stride32, u32 Lv, 
 // reciprocal pair (big,small).  coin=1 removes big->small.  Returns 1, or 0 if
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
-__device__ __forceinline__ int del_eval(const u32 *rows, u32 stride32, u32 Lv, int k,
+__device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
                                         u32 coin, u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     if (chain >= p.nchains) return;
 
     u32 *rows = p.rows + (size_t)chain * p.rows_per_chain;
+    const rsrc_t rrows = make_rows_rsrc(rows, p.rows_per_chain * 4ull);
     u32 *dbl = p.dbl + (size_t)chain * p.dbl_stride;
     u64 *cnt_g = (u64 *)p.counts + (size_t)chain * FCM_DEV_MAX_COUNTS;
     u64 *st_g = (u64 *)p.stats + (size_t)chain * FCM_DEV_NSTATS;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     int res = FCM_NEEDS_WIDE;
                     if (k + 2 <= WAVE) {
                         const u32 Lv = load_list(nb, off, k, a, b, lane);
-                        res = flip_eval<MAXT>(rows, stride32, Lv, k, Hs, Hp, lane, tmax, delta);
+                        res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hs, Hp, lane, tmax, delta);
                     }
                     if (res == FCM_NEEDS_WIDE) {
                         if (k + 2 <= 64 * maxnw) {
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             const int ck = (int)ce.k;
                             if (ck + 2 <= WAVE) {
                                 Lv2 = load_list(nb, ce.nb_off, ck, ce.big, ce.small, lane);
-                                myH2 = build_local(rows, stride32, Lv2, ck + 2, lane);
+                                myH2 = build_local(rrows, stride32, Lv2, ck + 2, lane);
                                 const u32 f = (u32)(rdlane64(myH2, ck) >> (ck + 1)) & 1u, bwd = (u32)(rdlane64(myH2, ck + 1) >> ck) & 1u;
                                 if (!(f | bwd)) status |= 1u;
                                 found = (f ^ bwd) != 0u;
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         if (!go_wide) {
                             // (1) remove delme: subtract simplices through it
                             const u32 Lv1 = load_list(nb, de.nb_off, dk, de.big, de.small, lane);
-                            const int r1 = del_eval<MAXT>(rows, stride32, Lv1, dk, coin, Hs, Hp, lane, tmax, delta);
+                            const int r1 = del_eval<MAXT>(rrows, stride32, Lv1, dk, coin, Hs, Hp, lane, tmax, delta);
                             go_wide = r1 == FCM_NEEDS_WIDE;
                             okd = r1 != 0;
                             if (!go_wide) {
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 // ---- clique_permute / clique_swap (src/lib.rs:214-290) -------
                 if constexpr (CLIQUE) {
                     const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
-                    const CliqueResult cr = clique_propose<MAXT>(p, rows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta);
+                    const CliqueResult cr = clique_propose<MAXT>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta);
                     status |= cr.status;
                     if (cr.nchg > 0) {
                         nonempty = true;
