@@ -106,10 +106,12 @@ def test_bounds_calculate_panics_like_the_reference(fcm):
 # ------------------------------------------------------------ trajectories ----
 def _run_parity(fcm, oracle, n, e, n_chains, steps, seed, weights=(0.5, 0.5, 0.0, 0.0), relaxation=0.01,
                 first_chain_id=0, check_chains=None, bounds=None):
-    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e, relaxation)
-    if bounds is not None:
+    if bounds is not None:   # hand-made bounds: Bounds::calculate is not involved (it panics on some tiny graphs)
+        gg, go = fcm.Graph.from_edges(n, e), oracle.Graph.from_edges(n, e)
         b_g = fcm.Bounds(*bounds)
         b_o = oracle.Bounds.from_lists(*bounds)
+    else:
+        gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e, relaxation)
     s = fcm.MCMCSampler(gg, b_g, n_chains=n_chains, seed=seed, move_weights=weights, first_chain_id=first_chain_id)
     check_chains = list(range(n_chains)) if check_chains is None else check_chains
     twins = {c: oracle.Chain(go, b_o, weights=weights, seed=seed, chain_id=first_chain_id + c) for c in check_chains}
@@ -551,3 +553,65 @@ def test_default_mix_config3_invariants(fcm):
         assert g.flagser_count() == fc
         assert (g.undirected_edges() == und0).all() and g.nedges() == len(e)
         assert s.bounds.check(s.flag_count(c))
+
+
+def _special_graphs():
+    """Small graphs that stress structural corner cases of the moves."""
+    rng = np.random.default_rng(11)
+    out = {}
+    # triangle-free: maximal cliques are edges (order 2) and isolated vertices (order 1)
+    e = [(i, i + 1) for i in range(0, 14)] + [(3, 2), (7, 6), (14, 0), (0, 14)]
+    out["cycle_with_doubles_and_isolated"] = (18, np.array(e, np.uint32))
+    # two disjoint 5-cliques (clique_swap with an empty intersection) plus a bridge
+    e = []
+    for base in (0, 5):
+        for i in range(5):
+            for j in range(i):
+                r = rng.random()
+                e += [(base + i, base + j)] if r < 0.45 else ([(base + j, base + i)] if r < 0.9 else [(base + i, base + j), (base + j, base + i)])
+    e += [(4, 5)]
+    out["two_disjoint_5_cliques"] = (10, np.array(e, np.uint32))
+    # one 6-clique made of reciprocal pairs only (every permutation is the identity move)
+    e = [(i, j) for i in range(6) for j in range(6) if i != j]
+    out["all_reciprocal_6_clique"] = (6, np.array(e, np.uint32))
+    # overlapping cliques sharing a 3-clique core (clique_swap with a large intersection)
+    e = []
+    core = [0, 1, 2]
+    groups = [core + [3, 4], core + [5, 6], core + [7, 8]]
+    seen = set()
+    for g in groups:
+        for i in g:
+            for j in g:
+                if i < j and (i, j) not in seen:
+                    seen.add((i, j))
+                    r = rng.random()
+                    e += [(i, j)] if r < 0.4 else ([(j, i)] if r < 0.8 else [(i, j), (j, i)])
+    out["three_5_cliques_sharing_a_triangle"] = (9, np.array(e, np.uint32))
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(_special_graphs()))
+@pytest.mark.parametrize("weights", [(0.25, 0.25, 0.25, 0.25), (0.0, 0.0, 0.5, 0.5)])
+def test_special_graphs_all_moves_parity(fcm, oracle, name, weights):
+    n, e = _special_graphs()[name]
+    go = oracle.Graph.from_edges(n, e)
+    fc = go.flagser_count()
+    # hand-made bounds: generous on every dimension the undirected cliques allow, so moves are mostly accepted
+    # but some are rejected (tight on dimension 2)
+    ncl = oracle.State(go).clique_counts()
+    width = max(len(ncl), len(fc)) + 1
+    mn = [fc[0], fc[1]] + [0] * (width - 2)
+    mx = [fc[0], fc[1]] + [10 ** 6] * (width - 2)
+    if len(fc) > 2:
+        mn[2], mx[2] = max(0, fc[2] - 6), fc[2] + 6
+    s, tw = _run_parity(fcm, oracle, n, e, n_chains=3, steps=[1, 2, 61, 64, 130], seed=8, weights=weights, bounds=(mn, mx))
+    st = s.stats()
+    assert (st["sampled"] == 258).all()
+    assert (st["n_empty"] + st["n_flip"] + st["n_dmove"] + st["n_cperm"] + st["n_cswap"] == 258).all()
+
+
+def test_single_chain_and_odd_launch_sizes(fcm, oracle):
+    from flag_complex_mcmc_amd import graphs
+    e = graphs.random_with_p(90, 0.2, seed=12)
+    # n_chains = 1; launches of 0, 1, 63, 64, 65, 127 proposals; default mix
+    _run_parity(fcm, oracle, 90, e, n_chains=1, steps=[0, 1, 63, 64, 65, 127, 0, 3], seed=21, weights=(0.1, 0.1, 0.6, 0.2), relaxation=0.05)
