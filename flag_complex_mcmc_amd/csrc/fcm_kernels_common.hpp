@@ -138,6 +138,21 @@ __device__ __forceinline__ void wrlane64(u64 m, int l, u32 &lo, u32 &hi)
                  : "+v"(lo), "+v"(hi) : "s"((u32)m), "s"((u32)(m >> 32)), "s"(l) : "m0");
 }
 
+// one guarded batch: rows i0 .. min(i0+N, s)
+template <int N>
+__device__ __forceinline__ void build_batch_guarded(const rsrc_t rsrc, u32 voff, u32 bmask, u32 roff, int i0, int s, u32 &hlo, u32 &hhi)
+{
+    u32 w[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        w[q] = 0u;
+        if (i0 + q < s) w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        if (i0 + q < s) wrlane64(ballot((w[q] & bmask) != 0u), i0 + q, hlo, hhi);
+}
+
 __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 Lv, int s, int lane)
 {
     const bool act = lane < s;
@@ -145,25 +160,33 @@ __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 
     const u32 bmask = act ? (1u << (Lv & 31u)) : 0u;     // inactive lanes never set a bit
     const u32 roff = Lv * (stride32 * 4u);               // byte offset of row Lv; read back per row by v_readlane
     u32 hlo = 0u, hhi = 0u;                              // this lane's row, written by v_writelane
-    int i0 = 0;
-    for (; i0 + FCM_HB <= s; i0 += FCM_HB) {             // full batches: FCM_HB row reads in flight
-        u32 w[FCM_HB];
+    if (s <= 8) {                                        // sparse graphs: a handful of rows
+        build_batch_guarded<8>(rsrc, voff, bmask, roff, 0, s, hlo, hhi);
+    } else if (s <= FCM_HB) {
+        build_batch_guarded<FCM_HB>(rsrc, voff, bmask, roff, 0, s, hlo, hhi);
+    } else {
+        // FCM_HB unguarded rows plus up to FCM_HB guarded ones per trip, and the loads of BOTH
+        // batches are issued before either is consumed: a local set of up to 2*FCM_HB vertices
+        // costs one memory round trip, not two.
+        int i0 = 0;
+        for (; i0 + FCM_HB <= s; i0 += 2 * FCM_HB) {
+            u32 wa[FCM_HB], wb[FCM_HB];
 #pragma unroll
-        for (int q = 0; q < FCM_HB; ++q)                 // buffer_load_dword v, voff, rsrc, soffset: no address arithmetic
-            w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
+            for (int q = 0; q < FCM_HB; ++q)             // buffer_load_dword v, voff, rsrc, soffset: no address arithmetic
+                wa[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
+            const int i1 = i0 + FCM_HB;
 #pragma unroll
-        for (int q = 0; q < FCM_HB; ++q) wrlane64(ballot((w[q] & bmask) != 0u), i0 + q, hlo, hhi);
-    }
-    if (i0 < s) {                                        // last, partial batch: only the rows that exist
-        u32 w[FCM_HB];
+            for (int q = 0; q < FCM_HB; ++q) {
+                wb[q] = 0u;
+                if (i1 + q < s) wb[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i1 + q), 0);
+            }
 #pragma unroll
-        for (int q = 0; q < FCM_HB; ++q) {
-            w[q] = 0u;
-            if (i0 + q < s) w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
+            for (int q = 0; q < FCM_HB; ++q) wrlane64(ballot((wa[q] & bmask) != 0u), i0 + q, hlo, hhi);
+#pragma unroll
+            for (int q = 0; q < FCM_HB; ++q)
+                if (i1 + q < s) wrlane64(ballot((wb[q] & bmask) != 0u), i1 + q, hlo, hhi);
         }
-#pragma unroll
-        for (int q = 0; q < FCM_HB; ++q)
-            if (i0 + q < s) wrlane64(ballot((w[q] & bmask) != 0u), i0 + q, hlo, hhi);
+        if (i0 < s) build_batch_guarded<FCM_HB>(rsrc, voff, bmask, roff, i0, s, hlo, hhi);  // s > 2*FCM_HB: the tail
     }
     return (u64)hlo | ((u64)hhi << 32);  // lanes >= s were never written: 0
 }
