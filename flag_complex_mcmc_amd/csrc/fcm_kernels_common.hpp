@@ -724,6 +724,10 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             bool nonempty = false, used_wide = false;
             // pending commit (uniform)
             u32 c_clr_from = 0, c_clr_to = 0, c_set_from = 0, c_set_to = 0;
+            // the two bitmap words a commit rewrites, read while the build is in flight so that the
+            // commit is two plain stores instead of two read-modify-write round trips
+            u32 c_clr_old = 0, c_set_old = 0;
+            bool c_have_old = false;
             u32 c_slot = 0, c_newdbl = 0;
             bool is_dmove = false;
             int clq_nchg = 0, clq_nd = 0;
@@ -736,6 +740,10 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     const u32 off = rdlane(l_e.nb_off, sidx);
                     const int k = (int)rdlane(l_e.k, sidx);
                     int res = FCM_NEEDS_WIDE;
+                    // (tiny local sets: the build reads these very words, a read-modify-write then hits cache)
+                    const bool pre = k + 2 > 8;
+                    u32 w_ab = 0u, w_ba = 0u;
+                    if (pre) { w_ab = rows[(size_t)a * stride32 + (b >> 5)]; w_ba = rows[(size_t)b * stride32 + (a >> 5)]; }
                     if (k + 2 <= WAVE) {
                         const u32 Lv = load_list(nb, off, k, a, b, lane);
                         res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hs, Hp, lane, tmax, delta);
@@ -755,6 +763,8 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         nonempty = true;
                         c_clr_from = res == 1 ? a : b; c_clr_to = res == 1 ? b : a;
                         c_set_from = c_clr_to; c_set_to = c_clr_from;
+                        c_clr_old = res == 1 ? w_ab : w_ba; c_set_old = res == 1 ? w_ba : w_ab;
+                        c_have_old = pre;
                         sum_k += (u64)k;
                     }
                 }
@@ -818,6 +828,11 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         const u32 dfrom = coin ? de.big : de.small, dto = coin ? de.small : de.big;
                         nonempty = true; is_dmove = true;
                         const int dk = (int)de.k;
+                        if (dk + 2 > 8 || (int)ce.k + 2 > 8) {
+                            c_clr_old = rows[(size_t)dfrom * stride32 + (dto >> 5)];
+                            c_set_old = rows[(size_t)eb * stride32 + (ea >> 5)];
+                            c_have_old = true;
+                        }
                         bool go_wide = dk + 2 > WAVE || rk + 2 > WAVE;
                         bool okd = true;
                         if (!go_wide) {
@@ -911,9 +926,19 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     } else {
                         if (lane == 0) {
                             u32 *pc = rows + (size_t)c_clr_from * stride32 + (c_clr_to >> 5);
-                            *pc &= ~(1u << (c_clr_to & 31u));
                             u32 *ps = rows + (size_t)c_set_from * stride32 + (c_set_to >> 5);
-                            *ps |= (1u << (c_set_to & 31u));
+                            const u32 bc = 1u << (c_clr_to & 31u), bs = 1u << (c_set_to & 31u);
+                            if (c_have_old) {
+                                if (pc == ps) {   // both changes in one word (double-edge move only)
+                                    *pc = (c_clr_old & ~bc) | bs;
+                                } else {
+                                    *pc = c_clr_old & ~bc;
+                                    *ps = c_set_old | bs;
+                                }
+                            } else {
+                                *pc &= ~bc;
+                                *ps |= bs;
+                            }
                             if (is_dmove) {
                                 if constexpr (CLIQUE) {
                                     slot_of[dbl[c_slot]] = FCM_NOSLOT;
