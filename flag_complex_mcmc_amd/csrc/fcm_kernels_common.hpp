@@ -709,6 +709,15 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             l_c1 = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
             if (l_c0 < U) l_e = p.etab[l_c0];  // candidate 0 wins ~9 times in 10: have its table entry ready
         }
+        // ... and the reciprocal pair its slot names *now*.  The slot list is mutable, so this is a
+        // guess (right unless that very slot is rewritten within the next 64 proposals); the move
+        // re-reads the slot in the same round trip as its vertex lists and falls back if it changed.
+        u32 l_ed = 0u;
+        FcmEdgeEntry l_de = {0u, 0u, 0u, 0u};
+        if (l_move == 1 && D > 0) {
+            l_ed = dbl[(u32)l_idx];
+            l_de = p.etab[l_ed];
+        }
 
         const int nbatch = (int)min((u64)WAVE, p.nprop - done);
         for (int sidx = 0; sidx < nbatch; ++sidx) {
@@ -772,8 +781,12 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 // ---- double_edge_move (src/lib.rs:304-325) -----------------
                 if (D > 0) {
                     const u32 slot = (u32)idx;
-                    const u32 ed = dbl[slot];
-                    const FcmEdgeEntry de = p.etab[ed];
+                    const u32 ed = dbl[slot];                       // the live entry ...
+                    FcmEdgeEntry de;                                // ... and the batch pass's guess of its pair
+                    const u32 ed_guess = rdlane(l_ed, sidx);
+                    de.big = rdlane(l_de.big, sidx); de.small = rdlane(l_de.small, sidx);
+                    de.nb_off = rdlane(l_de.nb_off, sidx); de.k = rdlane(l_de.k, sidx);
+                    u32 Lv1 = ((int)de.k + 2 <= WAVE) ? load_list(nb, de.nb_off, (int)de.k, de.big, de.small, lane) : 0u;
                     // Up to 64 candidate draws for the single edge (two per Philox block
                     // sub = 1..32), first valid in order wins (uniform directed edge, retry
                     // while reciprocal: :308-313).  Candidates 0 and 1 come from the batch
@@ -820,6 +833,10 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         have_ce = false;
                     }
                     if (found) {
+                        if (ed != ed_guess) {   // the slot was rewritten since the batch draw: take the live pair
+                            de = p.etab[ed];
+                            Lv1 = ((int)de.k + 2 <= WAVE) ? load_list(nb, de.nb_off, (int)de.k, de.big, de.small, lane) : 0u;
+                        }
                         const u32 r = (u32)cand;
                         const u32 rbig = ce.big, rsmall = ce.small, roff = ce.nb_off;
                         const int rk = (int)ce.k;
@@ -837,7 +854,6 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         bool okd = true;
                         if (!go_wide) {
                             // (1) remove delme: subtract simplices through it
-                            const u32 Lv1 = load_list(nb, de.nb_off, dk, de.big, de.small, lane);
                             const int r1 = del_eval<MAXT>(rrows, stride32, Lv1, dk, coin, Hs, Hp, lane, tmax, delta);
                             go_wide = r1 == FCM_NEEDS_WIDE;
                             okd = r1 != 0;
