@@ -8,9 +8,9 @@
 #define FCM_CAT3(a, b, c, d) a##b##c##d
 #define FCM_CAT(a, b, c, d) FCM_CAT3(a, b, c, d)
 
-// MAXT=6 without clique moves serves the BASELINE configs (<= 8 count entries):
-// keep >= 4 waves/SIMD so that 4096 chains (16 waves per CU) are resident at once.
-#if FCM_MAXT <= 6 && !FCM_CLIQUE
+// MAXT=6 serves the BASELINE configs (<= 8 count entries): keep >= 4 waves/SIMD
+// (at most 128 VGPRs) so that 4096 chains (16 waves per CU) are resident at once.
+#if FCM_MAXT <= 6
 #define FCM_MINW 4
 #else
 #define FCM_MINW 1

@@ -44,7 +44,8 @@ def run(name, n, edges, chains, proposals, launches, dim_cap=0):
         nc = s.ncounts
         pad = lambda v: (list(v) + [0] * nc)[:nc]
         ok &= (full == strip(got)) if s.info["lossless"] else (pad(full) == pad(got))
-        ok &= b.check(s.flag_count(c))
+        if s.info["lossless"]:   # (the full-length bounds are not meaningful against a truncated count vector)
+            ok &= b.check(s.flag_count(c))
     ab = algorithmic_bytes(d, n)
     print(json.dumps({"config": name, "n": n, "m": int(len(edges)), "chains": chains, "proposals_per_launch": proposals,
                       "launches": launches, "setup_s": round(t_setup, 2), "flag_count": fc, "ncliques_len": len(ncl),
