@@ -88,6 +88,7 @@ SIGNATURES = {
     "fcm_sampler_get_edgebits": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint64, u64p]),
     "fcm_sampler_get_double_slots": (C.c_int, [vp, C.c_uint32, u32p, C.c_uint64, u64p]),
     "fcm_sampler_get_info": (C.c_int, [vp, C.POINTER(CSamplerInfo)]),
+    "fcm_sampler_debug_stamps": (C.c_int, [vp, u64p]),
     "fcm_sampler_get_bounds": (C.c_int, [vp, C.POINTER(CBounds)]),
     "fcm_sampler_save_state": (C.c_int, [vp, C.c_char_p, C.c_uint64]),
     "fcm_sampler_load_state": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp), u64p]),

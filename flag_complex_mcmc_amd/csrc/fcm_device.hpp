@@ -44,6 +44,7 @@ struct FcmStepParams {
     uint64_t cum2;             // clique_permute if w0 < cum2, else clique_swap
     int32_t cl_orders;         // cliques_by_order.len()
     uint32_t chg_cap;          // capacity of the change list in LDS (entries)
+    uint64_t *dbgbuf;          // [n_chains][8] cycle sums of a -DFCM_STAMP diagnostic build; unused otherwise
     int32_t ncounts;           // tracked count entries NC (<= 16)
     int32_t maxnw;             // mask words the largest local set needs: ceil((k_max+2)/64), 1..4
 };

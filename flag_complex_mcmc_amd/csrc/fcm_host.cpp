@@ -649,7 +649,7 @@ struct fcm_sampler {
     uint32_t n = 0, stride32 = 0;
     std::vector<uint32_t> ue;          // [U][2] big, small
     // device buffers
-    DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats, d_clq, d_efirst, d_slot_of;
+    DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats, d_clq, d_efirst, d_slot_of, d_dbg;
     bool clique_moves = false;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -821,6 +821,8 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
         for (uint32_t c = 0; c < C && U; ++c)
             HIP_TRY(hipMemcpy(s->d_slot_of.as<uint32_t>() + (size_t)c * U, so.data(), (size_t)U * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    if ((rc = s->d_dbg.alloc((size_t)C * 8 * sizeof(uint64_t)))) return rc;
+    HIP_TRY(hipMemset(s->d_dbg.p, 0, (size_t)C * 8 * sizeof(uint64_t)));
     HIP_TRY(hipStreamCreate(&s->own_stream));
     s->stream = s->own_stream;
     HIP_TRY(hipEventCreate(&s->ev0));
@@ -835,6 +837,7 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     p.dbl = s->d_dbl.as<uint32_t>();
     p.counts = s->d_counts.as<uint64_t>();
     p.stats = s->d_stats.as<uint64_t>();
+    p.dbgbuf = s->d_dbg.as<uint64_t>();
     for (int d = 0; d < FCM_MAX_COUNTS; ++d) {
         // zero padding of the shorter side, src/util.rs:53-57
         p.bmin[d] = d < bounds->min_len ? bounds->flag_count_min[d] : 0;
@@ -1197,5 +1200,16 @@ extern "C" int fcm_sampler_load_state(const char *path, int device, fcm_sampler 
     if (sample_number) *sample_number = h.sample_number;
     sg.s = nullptr;
     *out = s;
+    return FCM_OK;
+}
+
+
+// Diagnostic: the per-chain cycle sums a -DFCM_STAMP build accumulates (zeros in the product build).
+extern "C" int fcm_sampler_debug_stamps(fcm_sampler *s, uint64_t *out /* [n_chains][8] */)
+{
+    if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    int rc = fcm_sampler_sync(s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, s->d_dbg.p, (size_t)s->params.nchains * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return FCM_OK;
 }

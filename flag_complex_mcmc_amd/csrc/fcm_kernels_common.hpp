@@ -112,6 +112,28 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---------------------------------------------------------------------------
+// Diagnostic build only (-DFCM_STAMP): s_memtime stamps that drain every
+// counter first, accumulated per phase into the debug words of the stats row.
+// Never compiled into the product build; a stamped build's run time means
+// nothing, only the shares do (cdna_hip_programming.md, In-kernel stamps).
+// ---------------------------------------------------------------------------
+#ifdef FCM_STAMP
+__device__ __forceinline__ u64 fcm_stamp()
+{
+    u64 t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define FCM_STAMP_DECL u64 stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 stamp_t = fcm_stamp();
+#define FCM_STAMP_AT(slot) do { const u64 _n = fcm_stamp(); stamp_acc[slot] += _n - stamp_t; stamp_t = _n; } while (0)
+#else
+#define FCM_STAMP_DECL
+#define FCM_STAMP_AT(slot) do { } while (0)
+#endif
+
 // ===========================================================================
 // Fast evaluator: local sets of <= 64 vertices, one u64 mask per vertex
 // ===========================================================================
@@ -688,6 +710,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     // transition is "accepted", src/lib.rs:186-187)
     bool in_bounds = ballot(cl && (cnt < bmin || cnt > bmax)) == 0ull;
 
+    FCM_STAMP_DECL
     for (u64 done = 0; done < p.nprop; done += WAVE) {
         // ---- batch: lane s draws proposal `sampled + s` ------------------
         const u64 t = sampled + (u64)lane;
@@ -754,8 +777,34 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     u32 w_ab = 0u, w_ba = 0u;
                     if (pre) { w_ab = rows[(size_t)a * stride32 + (b >> 5)]; w_ba = rows[(size_t)b * stride32 + (a >> 5)]; }
                     if (k + 2 <= WAVE) {
+                        FCM_STAMP_AT(0);                               // decode
                         const u32 Lv = load_list(nb, off, k, a, b, lane);
+                        FCM_STAMP_AT(1);                               // flip: vertex list round trip
+#ifdef FCM_STAMP
+                        {   // same work as flip_eval, with a stamp between build and count
+                            u64 myH = build_local(rrows, stride32, Lv, k + 2, lane);
+                            FCM_STAMP_AT(2);                           // flip: build
+                            Hs[lane] = myH;
+                            wave_sync();
+                            const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
+                            if (ab == ba) res = ab ? 0 : -1;
+                            else {
+                                const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;
+                                Cls c = classify(myH, Hs, iu, iv);
+                                Cls c2; c2.P = c.P; c2.S = c.S;
+                                c2.M = Hs[iv] & ballot((myH >> iu) & 1ull) & ~(3ull << k);
+                                if (!extras_fit(c, k + 2) || !extras_fit(c2, k + 2)) res = FCM_NEEDS_WIDE;
+                                else {
+                                    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
+                                    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta);
+                                    res = ab ? 1 : 2;
+                                }
+                            }
+                            FCM_STAMP_AT(3);                           // flip: two evaluations
+                        }
+#else
                         res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hs, Hp, lane, tmax, delta);
+#endif
                     }
                     if (res == FCM_NEEDS_WIDE) {
                         if (k + 2 <= 64 * maxnw) {
@@ -780,6 +829,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             } else if (move == 1) {
                 // ---- double_edge_move (src/lib.rs:304-325) -----------------
                 if (D > 0) {
+                    FCM_STAMP_AT(0);
                     const u32 slot = (u32)idx;
                     const u32 ed = dbl[slot];                       // the live entry ...
                     FcmEdgeEntry de;                                // ... and the batch pass's guess of its pair
@@ -832,6 +882,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         }
                         have_ce = false;
                     }
+                    FCM_STAMP_AT(4);                                   // double move: lists + candidate build
                     if (found) {
                         if (ed != ed_guess) {   // the slot was rewritten since the batch draw: take the live pair
                             de = p.etab[ed];
@@ -876,6 +927,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                                 used_wide = true;
                             }
                         }
+                        FCM_STAMP_AT(5);                               // double move: second build + two evaluations
                         if (!okd) status |= 2u;  // slot list says reciprocal, bitmap says not
                         c_clr_from = dfrom; c_clr_to = dto;
                         c_set_from = eb; c_set_to = ea;
@@ -901,6 +953,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 }
             }
 
+            FCM_STAMP_AT(0);
             // ---- sampled += 1; Bounds::check; accept or drop ---------------
             sampled += 1;
             if (!nonempty) {
@@ -972,7 +1025,9 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     }
                 }
             }
+            FCM_STAMP_AT(6);                                           // reductions, bounds, commit
         }
+        FCM_STAMP_AT(7);                                               // (batch boundary)
     }
 
     if (cl) cnt_g[lane] = cnt;
@@ -980,5 +1035,8 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         st_g[0] = sampled; st_g[1] = accepted; st_g[2] = n_empty; st_g[3] = n_flip;
         st_g[4] = n_dmove; st_g[5] = sum_k; st_g[6] = count_len; st_g[7] = status;
         st_g[8] = n_cperm; st_g[9] = n_cswap; st_g[10] = n_changes;
+#ifdef FCM_STAMP
+        for (int q = 0; q < 8; ++q) p.dbgbuf[(size_t)chain * 8 + q] += stamp_acc[q];
+#endif
     }
 }

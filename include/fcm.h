@@ -214,6 +214,10 @@ int fcm_sampler_get_double_slots(fcm_sampler *s, uint32_t chain, uint32_t *out, 
 int fcm_sampler_save_state(fcm_sampler *s, const char *path, uint64_t sample_number);
 int fcm_sampler_load_state(const char *path, int device, fcm_sampler **out, uint64_t *sample_number);
 
+/* Diagnostic: per-chain phase cycle sums of a -DFCM_STAMP build of the step kernel
+ * (tools/run_stamps.sh); all zero in the product build.  out[n_chains][8]. */
+int fcm_sampler_debug_stamps(fcm_sampler *s, uint64_t *out);
+
 /* Static facts about the sampler (for bench accounting). */
 typedef struct {
     uint32_t n;                /* vertices */
