@@ -72,7 +72,7 @@ __device__ __forceinline__ u32 wrlane(u32 src, int l, u32 old)
     return (u32)__builtin_amdgcn_writelane((int)src, l, (int)old);
 #else
     // two SGPR sources would break the constant-bus limit: the lane select goes through m0
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(src), "s"(l) : "m0");
+    asm volatile("s_nop 0\n\ts_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(src), "s"(l) : "m0");
     return old;
 #endif
 }
@@ -153,28 +153,41 @@ __device__ __forceinline__ rsrc_t make_rows_rsrc(const u32 *rows, u64 bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void *)rows, 0, (int)(u32)bytes, 0x00020000);
 }
-// lane `l` of (lo, hi) := the wave-uniform 64-bit value m; one m0 write for both halves
-__device__ __forceinline__ void wrlane64(u64 m, int l, u32 &lo, u32 &hi)
+// lane L (a compile-time constant) of (lo, hi) := the wave-uniform 64-bit value m.  The lane
+// select is an inline constant, so the two SGPR halves are the only scalar operands.
+// s_nop 1: on gfx940+ a VALU write of an SGPR/VCC (the v_cmp that made m) needs two wait states
+// before a VALU reads it; hipcc pads that itself, but not across an asm boundary
+// (cdna_hip_programming.md 5.7).  Without it the masks come out wrong.
+template <int L>
+__device__ __forceinline__ void wrlane64c(u64 m, u32 &lo, u32 &hi)
 {
-    asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                 : "+v"(lo), "+v"(hi) : "s"((u32)m), "s"((u32)(m >> 32)), "s"(l) : "m0");
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi) : "s"((u32)m), "s"((u32)(m >> 32)), "n"(L));
 }
 
-// one guarded batch: rows i0 .. min(i0+N, s)
-template <int N>
-__device__ __forceinline__ void build_batch_guarded(const rsrc_t rsrc, u32 voff, u32 bmask, u32 roff, int i0, int s, u32 &hlo, u32 &hhi)
+// rows I0 .. I0+N-1 of the local adjacency (those below s when GUARDED): issue the reads ...
+template <int I0, int N, bool GUARDED>
+__device__ __forceinline__ void build_issue(const rsrc_t rsrc, u32 voff, u32 roff, int s, u32 (&w)[N])
 {
-    u32 w[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         w[q] = 0u;
-        if (i0 + q < s) w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
+        if (!GUARDED || I0 + q < s)  // buffer_load_dword v, voff, rsrc, soffset: no address arithmetic
+            w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, I0 + q), 0);
     }
-#pragma unroll
-    for (int q = 0; q < N; ++q)
-        if (i0 + q < s) wrlane64(ballot((w[q] & bmask) != 0u), i0 + q, hlo, hhi);
+}
+// ... and turn them into masks: the v_cmp result is the ballot, v_writelane drops it into lane I0+q
+template <int I0, int N, bool GUARDED, int Q = 0>
+__device__ __forceinline__ void build_consume(const u32 (&w)[N], u32 bmask, int s, u32 &hlo, u32 &hhi)
+{
+    if constexpr (Q < N) {
+        if (!GUARDED || I0 + Q < s) wrlane64c<I0 + Q>(ballot((w[Q] & bmask) != 0u), hlo, hhi);
+        build_consume<I0, N, GUARDED, Q + 1>(w, bmask, s, hlo, hhi);
+    }
 }
 
+// Every row index below is a compile-time constant (a local set has at most 64 rows), so the
+// per-row cost is v_readlane + buffer_load + v_and + v_cmp + 2 v_writelane and nothing else.
 __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 Lv, int s, int lane)
 {
     const bool act = lane < s;
@@ -183,32 +196,27 @@ __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 
     const u32 roff = Lv * (stride32 * 4u);               // byte offset of row Lv; read back per row by v_readlane
     u32 hlo = 0u, hhi = 0u;                              // this lane's row, written by v_writelane
     if (s <= 8) {                                        // sparse graphs: a handful of rows
-        build_batch_guarded<8>(rsrc, voff, bmask, roff, 0, s, hlo, hhi);
+        u32 w[8];
+        build_issue<0, 8, true>(rsrc, voff, roff, s, w);
+        build_consume<0, 8, true>(w, bmask, s, hlo, hhi);
     } else if (s <= FCM_HB) {
-        build_batch_guarded<FCM_HB>(rsrc, voff, bmask, roff, 0, s, hlo, hhi);
+        u32 w[FCM_HB];
+        build_issue<0, FCM_HB, true>(rsrc, voff, roff, s, w);
+        build_consume<0, FCM_HB, true>(w, bmask, s, hlo, hhi);
     } else {
-        // FCM_HB unguarded rows plus up to FCM_HB guarded ones per trip, and the loads of BOTH
-        // batches are issued before either is consumed: a local set of up to 2*FCM_HB vertices
-        // costs one memory round trip, not two.
-        int i0 = 0;
-        for (; i0 + FCM_HB <= s; i0 += 2 * FCM_HB) {
-            u32 wa[FCM_HB], wb[FCM_HB];
-#pragma unroll
-            for (int q = 0; q < FCM_HB; ++q)             // buffer_load_dword v, voff, rsrc, soffset: no address arithmetic
-                wa[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
-            const int i1 = i0 + FCM_HB;
-#pragma unroll
-            for (int q = 0; q < FCM_HB; ++q) {
-                wb[q] = 0u;
-                if (i1 + q < s) wb[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i1 + q), 0);
-            }
-#pragma unroll
-            for (int q = 0; q < FCM_HB; ++q) wrlane64(ballot((wa[q] & bmask) != 0u), i0 + q, hlo, hhi);
-#pragma unroll
-            for (int q = 0; q < FCM_HB; ++q)
-                if (i1 + q < s) wrlane64(ballot((wb[q] & bmask) != 0u), i1 + q, hlo, hhi);
+        // FCM_HB unguarded rows plus up to FCM_HB guarded ones, and the reads of BOTH batches are
+        // issued before either is consumed: a local set of up to 2*FCM_HB vertices costs one
+        // memory round trip, not two.
+        u32 wa[FCM_HB], wb[FCM_HB];
+        build_issue<0, FCM_HB, false>(rsrc, voff, roff, s, wa);
+        build_issue<FCM_HB, FCM_HB, true>(rsrc, voff, roff, s, wb);
+        build_consume<0, FCM_HB, false>(wa, bmask, s, hlo, hhi);
+        build_consume<FCM_HB, FCM_HB, true>(wb, bmask, s, hlo, hhi);
+        if (s > 2 * FCM_HB) {                            // rows 48..63
+            u32 wc[WAVE - 2 * FCM_HB];
+            build_issue<2 * FCM_HB, WAVE - 2 * FCM_HB, true>(rsrc, voff, roff, s, wc);
+            build_consume<2 * FCM_HB, WAVE - 2 * FCM_HB, true>(wc, bmask, s, hlo, hhi);
         }
-        if (i0 < s) build_batch_guarded<FCM_HB>(rsrc, voff, bmask, roff, i0, s, hlo, hhi);  // s > 2*FCM_HB: the tail
     }
     return (u64)hlo | ((u64)hhi << 32);  // lanes >= s were never written: 0
 }
