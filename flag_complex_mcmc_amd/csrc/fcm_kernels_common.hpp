@@ -186,36 +186,60 @@ __device__ __forceinline__ void build_consume(const u32 (&w)[N], u32 bmask, int 
     }
 }
 
+// A guarded batch of N slots costs a compare and a branch per slot, twice (issue, consume), so
+// it is instantiated in steps of four and the smallest size that holds `cnt` rows is used.
+template <int I0, int N>
+__device__ __forceinline__ void build_tail(const rsrc_t rsrc, u32 voff, u32 bmask, u32 roff, int s, u32 &hlo, u32 &hhi)
+{
+    u32 w[N];
+    build_issue<I0, N, true>(rsrc, voff, roff, s, w);
+    build_consume<I0, N, true>(w, bmask, s, hlo, hhi);
+}
+// the same with the unguarded batch `wa` (rows 0..FCM_HB-1) consumed between issue and consume
+// of the tail, so that all reads are in flight together
+template <int N>
+__device__ __forceinline__ void build_second(const rsrc_t rsrc, u32 voff, u32 bmask, u32 roff, int s, const u32 (&wa)[FCM_HB],
+                                             u32 &hlo, u32 &hhi)
+{
+    u32 wb[N];
+    build_issue<FCM_HB, N, true>(rsrc, voff, roff, s, wb);
+    build_consume<0, FCM_HB, false>(wa, bmask, s, hlo, hhi);
+    build_consume<FCM_HB, N, true>(wb, bmask, s, hlo, hhi);
+}
+
 // Every row index below is a compile-time constant (a local set has at most 64 rows), so the
 // per-row cost is v_readlane + buffer_load + v_and + v_cmp + 2 v_writelane and nothing else.
 __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 Lv, int s, int lane)
 {
+    static_assert(FCM_HB == 24, "the tiers below are written for 24-row batches");
     const bool act = lane < s;
     const u32 voff = act ? (Lv >> 5) * 4u : 0u;          // byte offset of this lane's dword inside a row
     const u32 bmask = act ? (1u << (Lv & 31u)) : 0u;     // inactive lanes never set a bit
     const u32 roff = Lv * (stride32 * 4u);               // byte offset of row Lv; read back per row by v_readlane
     u32 hlo = 0u, hhi = 0u;                              // this lane's row, written by v_writelane
-    if (s <= 8) {                                        // sparse graphs: a handful of rows
-        u32 w[8];
-        build_issue<0, 8, true>(rsrc, voff, roff, s, w);
-        build_consume<0, 8, true>(w, bmask, s, hlo, hhi);
-    } else if (s <= FCM_HB) {
-        u32 w[FCM_HB];
-        build_issue<0, FCM_HB, true>(rsrc, voff, roff, s, w);
-        build_consume<0, FCM_HB, true>(w, bmask, s, hlo, hhi);
+    if (s <= 24) {                                       // one guarded batch
+        if (s <= 4) build_tail<0, 4>(rsrc, voff, bmask, roff, s, hlo, hhi);
+        else if (s <= 8) build_tail<0, 8>(rsrc, voff, bmask, roff, s, hlo, hhi);
+        else if (s <= 12) build_tail<0, 12>(rsrc, voff, bmask, roff, s, hlo, hhi);
+        else if (s <= 16) build_tail<0, 16>(rsrc, voff, bmask, roff, s, hlo, hhi);
+        else if (s <= 20) build_tail<0, 20>(rsrc, voff, bmask, roff, s, hlo, hhi);
+        else build_tail<0, 24>(rsrc, voff, bmask, roff, s, hlo, hhi);
     } else {
-        // FCM_HB unguarded rows plus up to FCM_HB guarded ones, and the reads of BOTH batches are
-        // issued before either is consumed: a local set of up to 2*FCM_HB vertices costs one
-        // memory round trip, not two.
-        u32 wa[FCM_HB], wb[FCM_HB];
+        // 24 unguarded rows plus a guarded tail, and the reads of BOTH are issued before either is
+        // consumed: a local set of up to 48 vertices costs one memory round trip, not two.
+        u32 wa[FCM_HB];
         build_issue<0, FCM_HB, false>(rsrc, voff, roff, s, wa);
-        build_issue<FCM_HB, FCM_HB, true>(rsrc, voff, roff, s, wb);
-        build_consume<0, FCM_HB, false>(wa, bmask, s, hlo, hhi);
-        build_consume<FCM_HB, FCM_HB, true>(wb, bmask, s, hlo, hhi);
-        if (s > 2 * FCM_HB) {                            // rows 48..63
-            u32 wc[WAVE - 2 * FCM_HB];
-            build_issue<2 * FCM_HB, WAVE - 2 * FCM_HB, true>(rsrc, voff, roff, s, wc);
-            build_consume<2 * FCM_HB, WAVE - 2 * FCM_HB, true>(wc, bmask, s, hlo, hhi);
+        if (s <= 28) build_second<4>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
+        else if (s <= 32) build_second<8>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
+        else if (s <= 36) build_second<12>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
+        else if (s <= 40) build_second<16>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
+        else if (s <= 44) build_second<20>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
+        else {
+            build_second<24>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
+            if (s > 48) {                                // rows 48..63
+                if (s <= 56) build_tail<48, 8>(rsrc, voff, bmask, roff, s, hlo, hhi);
+                else build_tail<48, 16>(rsrc, voff, bmask, roff, s, hlo, hhi);
+            }
         }
     }
     return (u64)hlo | ((u64)hhi << 32);  // lanes >= s were never written: 0
