@@ -8,11 +8,17 @@
 //     NEW[pd[i]][pd[j]] = OLD[i][j]      over the pairs (i,j) it touches,
 // where OLD is the current adjacency among d.  OLD is gathered as one 32-bit
 // row mask per lane, the column permutation is a handful of bit moves, the row
-// permutation one LDS scatter; ADD = NEW & ~OLD and REM = OLD & ~NEW are the
-// reference's change_edges (as a set).  The changes are then applied to the
-// bitmap one at a time, each counted exactly like a simple move's edge
-// (subtract E before a removal, add E after an addition); on a rejection the
-// bits are put back (State::revert_transition, src/lib.rs:81-95).
+// permutation one LDS scatter; NEW ^ OLD is the reference's change_edges (as a
+// set).  The changes are applied to the bitmap one vertex pair at a time.  The
+// number of simplices through a->b does not depend on whether b->a is there
+// (a simplex holds a and b in one order only), and the vertex classes around
+// the pair do not depend on the pair's own two bits, so one build of the
+// pair's neighbourhood serves both of its directions: a removal subtracts
+// E(a->b), an addition adds it, both on the graph with every earlier pair's
+// changes in place -- the same telescoping sum as the reference's edge-by-edge
+// State::apply_transition.  Pair ids come from the static per-clique table
+// clq_pairs; on a rejection the bits are put back (State::revert_transition,
+// src/lib.rs:81-95).
 #pragma once
 
 #define FCM_CHG_ADD 0x80000000u
@@ -23,10 +29,13 @@ struct CliqueLds {
     u32 *rowbuf;  // [32] scatter buffer for the row permutation
     u32 *oldm;    // [32] OLD rows
     u32 *newm;    // [32] NEW rows
-    u32 *chg;     // [chg_cap][2] change list: from, to | FCM_CHG_ADD
+    u32 *p1;      // [32] position of d[x] in the first clique (FCM_NOSLOT: not a member)
+    u32 *p2;      // [32] ... in the second clique
+    u32 *chg;     // changed vertex pairs, 4 words each: i | j<<8 | old<<16 | new<<20 (d indices i<j; bit 0 = i->j, bit 1 = j->i),
+                  // etab index, k, nb_off
 };
 // u64 words of LDS behind the evaluator region
-__host__ __device__ inline unsigned fcm_clique_lds_words(unsigned chg_cap) { return 64u + chg_cap; }
+__host__ __device__ inline unsigned fcm_clique_lds_words(unsigned chg_cap) { return 96u + chg_cap; }
 __device__ __forceinline__ CliqueLds clique_carve(u64 *base)
 {
     CliqueLds L;
@@ -34,27 +43,13 @@ __device__ __forceinline__ CliqueLds clique_carve(u64 *base)
     L.rowbuf = L.d + 32;
     L.oldm = L.d + 64;
     L.newm = L.d + 96;
-    L.chg = L.d + 128;
+    L.p1 = L.d + 128;
+    L.p2 = L.d + 160;
+    L.chg = L.d + 192;
     return L;
 }
 
-// one evaluation of an edge present in the bitmap: fast path, FCM_NEEDS_WIDE if it does not fit
-template <int MAXT>
-__device__ __forceinline__ int edge_eval(const rsrc_t rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
-                                         u32 fwd, int sign, u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
-{
-    const int s = k + 2;
-    const u32 Lv = lane < k ? nb[off + lane] : (lane == k ? big : small);
-    const u64 myH = build_local(rows, stride32, Lv, s, lane);
-    Hs[lane] = myH;
-    wave_sync();
-    const int iu = fwd ? k : k + 1, iv = fwd ? k + 1 : k;
-    const u32 present = (u32)((Hs[iu] >> iv) & 1ull);
-    const Cls c = classify(myH, Hs, iu, iv);
-    if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
-    eval_nodes<MAXT>(myH, Hp, c, k, tmax, sign, lane, delta);
-    return (int)present;
-}
+// one evaluation of an edge present in the bitmap on the wide path
 __device__ __forceinline__ bool wide_edge(const Wide W, const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big,
                                           u32 small, u32 fwd, int sign, int lane, int tmax)
 {
@@ -87,15 +82,15 @@ __device__ __forceinline__ u32 mulhi32(u32 w, u32 m) { return __umulhi(w, m); }
 
 struct CliqueResult {
     int nchg;         // directed edges changed (0 = empty transition)
-    int n_d;          // vertices involved
+    int npairs;       // vertex pairs with a change (entries of CL.chg)
     u64 sum_k;
     long long wide_d; // this lane's share of deltas that came through the wide path
     u32 status;
 };
 
-// Builds the change list of a clique move and applies it to the bitmap, adding
-// the simplex-count change to `delta` (fast evaluations) and res.wide_d (wide).
-// move == 2: clique_permute, 3: clique_swap.
+// Builds the changed-pair list of a clique move and applies it to the bitmap,
+// adding the simplex-count change to `delta` (fast evaluations) and res.wide_d
+// (wide).  move == 2: clique_permute, 3: clique_swap.
 template <int MAXT>
 __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, const rsrc_t rrows, u64 *smem, const CliqueLds CL, int move,
                                                        u32 w1, u64 x64, u64 step, u32 gchain, u32 k0, u32 k1, int lane, int tmax,
@@ -112,17 +107,24 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
     if (cnt == 0) { res.status = 16u; return res; }
     const u32 *bucket = p.clq + p.cl_base[oi];
     const u32 NONE = 0xFFFFFFFFu;
-    const u32 m1 = lane < o ? bucket[__umul64hi(x64, cnt) * (u64)o + lane] : NONE;
+    const u64 c1 = __umul64hi(x64, cnt);
+    u64 c2 = c1;
+    const u32 m1 = lane < o ? bucket[c1 * (u64)o + lane] : NONE;
     int n_c = o, n_a = 0, n_d = o;
     u32 dv = m1;  // d[lane]
+    if (lane < 32) { CL.p1[lane] = lane < o ? (u32)lane : NONE; CL.p2[lane] = NONE; }
     if (move == 3) {
         u32 v[4];
         philox4x32_10((u32)step, (u32)(step >> 32), gchain, 1u, k0, k1, v);
-        const u32 m2 = lane < o ? bucket[__umul64hi((u64)v[0] | ((u64)v[1] << 32), cnt) * (u64)o + lane] : NONE;
+        c2 = __umul64hi((u64)v[0] | ((u64)v[1] << 32), cnt);
+        const u32 m2 = lane < o ? bucket[c2 * (u64)o + lane] : NONE;
         bool in2 = false, in1 = false;  // m1[lane] in m2, m2[lane] in m1
+        int j1 = 0;                     // where m2[lane] sits in m1
         for (int j = 0; j < o; ++j) {
             in2 = in2 || (m1 == rdlane(m2, j));
-            in1 = in1 || (m2 == rdlane(m1, j));
+            const bool hit = m2 == rdlane(m1, j);
+            in1 = in1 || hit;
+            if (hit) j1 = j;
         }
         const u64 omask = (1ull << o) - 1ull;
         const u64 cm1 = ballot(lane < o && in2), cm2 = ballot(lane < o && in1);
@@ -130,16 +132,19 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
         n_a = o - n_c;
         n_d = o + n_a;
         const u64 below = (1ull << lane) - 1ull;
+        wave_sync();
         // d = c ++ (m1 - c) ++ (m2 - c), each part in its clique's order (vec_intersect / vec_setminus, src/util.rs:34-50)
         if (lane < o) {
             const int pos1 = in2 ? __popcll(cm1 & below) : n_c + __popcll(~cm1 & omask & below);
             CL.d[pos1] = m1;
-            if (!in1) CL.d[n_c + n_a + __popcll(~cm2 & omask & below)] = m2;
+            CL.p1[pos1] = (u32)lane;
+            const int pos2 = in1 ? __popcll(cm1 & ((1ull << j1) - 1ull)) : n_c + n_a + __popcll(~cm2 & omask & below);
+            if (!in1) CL.d[pos2] = m2;
+            CL.p2[pos2] = (u32)lane;
         }
         wave_sync();
         dv = lane < n_d ? CL.d[lane] : NONE;
     }
-    res.n_d = n_d;
     // ---- perm / perm_d (random_perm = Fisher-Yates over Philox words, blocks sub = 2, 3, ...)
     u32 ws[4];
     philox4x32_10((u32)step, (u32)(step >> 32), gchain, 2u + (u32)lane, k0, k1, ws);  // lane l holds words 4l..4l+3
@@ -185,87 +190,152 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
         const u32 pj = rdlane(pd, j);
         t |= ((oldr >> j) & 1u) << pj;
     }
-    if (act) { CL.rowbuf[pd] = t; CL.oldm[lane] = oldr; }
+    if (act) { CL.rowbuf[pd] = t; CL.oldm[lane] = oldr; CL.d[lane] = dv; }
     wave_sync();
     const u32 newr = act ? CL.rowbuf[lane] : 0u;
     if (act) CL.newm[lane] = newr;
-    const u32 addm = newr & ~oldr, remm = oldr & ~newr;
-    // ---- change list (src/lib.rs:226-228, 277-287), order immaterial
-    const int mine = __popc(addm) + __popc(remm);
+    // ---- change_edges (src/lib.rs:226-228, 277-287) = OLD ^ NEW, grouped per vertex pair
+    const int nchg = wave_sum_i32(__popc(oldr ^ newr));
+    res.nchg = nchg;
+    if (nchg == 0) return res;
+    wave_sync();
+    u32 oldt = 0u, newt = 0u;  // transposes: bit j = row j has bit `lane`
+    for (int j = 0; j < n_d; ++j) {
+        oldt |= ((CL.oldm[j] >> lane) & 1u) << j;
+        newt |= ((CL.newm[j] >> lane) & 1u) << j;
+    }
+    const u32 upper = act ? ~((2u << lane) - 1u) : 0u;  // each pair once: j > lane
+    const u32 chm = ((oldr ^ newr) | (oldt ^ newt)) & upper;
+    const int mine = __popc(chm);
     int inc = mine;
 #pragma unroll
     for (int sft = 1; sft < WAVE; sft <<= 1) {
         const int y = __shfl_up(inc, sft, WAVE);
         if (lane >= sft) inc += y;
     }
-    const int nchg = (int)rdlane((u32)inc, WAVE - 1);
-    res.nchg = nchg;
-    if (nchg == 0) return res;
-    if ((u32)nchg > p.chg_cap) { res.status = 32u; res.nchg = 0; return res; }
-    // d[] in LDS for both moves (clique_permute has not written it yet)
-    if (act) CL.d[lane] = dv;
-    wave_sync();
+    const int npairs = (int)rdlane((u32)inc, WAVE - 1);
+    if (4u * (u32)npairs > 2u * p.chg_cap) { res.status = 32u; res.nchg = 0; return res; }
+    res.npairs = npairs;
     {
         int pos = inc - mine;
-        for (u32 m = addm; m; m &= m - 1, ++pos) {
-            CL.chg[2 * pos] = dv;
-            CL.chg[2 * pos + 1] = CL.d[__ffs((int)m) - 1] | FCM_CHG_ADD;
-        }
-        for (u32 m = remm; m; m &= m - 1, ++pos) {
-            CL.chg[2 * pos] = dv;
-            CL.chg[2 * pos + 1] = CL.d[__ffs((int)m) - 1];
+        for (u32 m = chm; m; m &= m - 1, ++pos) {
+            const int j = __ffs((int)m) - 1;
+            const u32 o2 = ((oldr >> j) & 1u) | (((oldt >> j) & 1u) << 1), n2 = ((newr >> j) & 1u) | (((newt >> j) & 1u) << 1);
+            CL.chg[4 * pos] = (u32)lane | ((u32)j << 8) | (o2 << 16) | (n2 << 20);
         }
     }
     wave_sync();
-    // ---- apply one change at a time, counting each
-    for (int c = 0; c < nchg; ++c) {
-        const u32 from = CL.chg[2 * c], tw = CL.chg[2 * c + 1];
-        const u32 to = tw & ~FCM_CHG_ADD;
-        const bool add = (tw & FCM_CHG_ADD) != 0u;
-        const u32 big = from > to ? from : to, small = from > to ? to : from;
-        const u32 fwd = from > to ? 1u : 0u;
-        const u32 e = find_pair(p.etab, p.efirst, big, small, lane);
-        if (e == FCM_NOSLOT) { res.status |= 1u; continue; }
-        const FcmEdgeEntry de = p.etab[e];
-        const int k = (int)de.k;
-        u32 *word = rows + (size_t)from * stride32 + (to >> 5);
-        const u32 bit = 1u << (to & 31u);
-        if (add) {
-            if (lane == 0) *word |= bit;
-            wave_sync();
+    // ---- table entries of all changed pairs, in parallel
+    {
+        const u32 *ptab = p.clq_pairs + p.clp_base[oi];
+        const u32 npo = (u32)(o * (o - 1) / 2);
+        bool bad = false;
+        for (int x = lane; x < npairs; x += WAVE) {
+            const u32 w0 = CL.chg[4 * x];
+            const u32 di = w0 & 0xFFu, dj = (w0 >> 8) & 0xFFu;
+            u32 pa = CL.p1[di], pb = CL.p1[dj];
+            u64 ci = c1;
+            if (pa == NONE || pb == NONE) { pa = CL.p2[di]; pb = CL.p2[dj]; ci = c2; }
+            const u32 lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
+            u32 e = 0u;
+            if (hi < (u32)o && lo != hi) e = ptab[ci * npo + lo * (u32)o - lo * (lo + 1u) / 2u + (hi - lo - 1u)];
+            else bad = true;
+            const FcmEdgeEntry ent = p.etab[e];
+            const u32 a = CL.d[di], b = CL.d[dj];
+            bad = bad || ent.big != (a > b ? a : b) || ent.small != (a > b ? b : a);
+            CL.chg[4 * x + 1] = e;
+            CL.chg[4 * x + 2] = ent.k;
+            CL.chg[4 * x + 3] = ent.nb_off;
         }
-        int r = FCM_NEEDS_WIDE;
-        if (k + 2 <= WAVE) r = edge_eval<MAXT>(rrows, stride32, p.nb, de.nb_off, k, big, small, fwd, add ? +1 : -1, Hs, Hp, lane, tmax, delta);
-        if (r == FCM_NEEDS_WIDE) {
-            if (k + 2 <= 64 * maxnw) {
-                const Wide W = wide_carve(smem, maxnw);
-                wide_zero_counts(W, lane);
-                r = wide_edge(W, rows, stride32, p.nb, de.nb_off, k, big, small, fwd, add ? +1 : -1, lane, tmax) ? 1 : 0;
-                if (lane >= 2 && lane < 16 && lane - 1 <= tmax) res.wide_d += W.cnt[lane - 1];
+        if (ballot(bad)) { res.status = 1u; res.nchg = 0; res.npairs = 0; return res; }
+    }
+    wave_sync();
+    // ---- apply one pair at a time, counting each directed change
+    for (int x = 0; x < npairs; ++x) {
+        const u32 w0 = CL.chg[4 * x], off = CL.chg[4 * x + 3];
+        const int k = (int)CL.chg[4 * x + 2];
+        const u32 a = CL.d[w0 & 0xFFu], b = CL.d[(w0 >> 8) & 0xFFu];
+        const u32 o2 = (w0 >> 16) & 3u, n2 = (w0 >> 20) & 3u;
+        const bool agb = a > b;
+        const u32 big = agb ? a : b, small = agb ? b : a;
+        // directions in (big, small) terms
+        const u32 o_bs = agb ? (o2 & 1u) : (o2 >> 1), o_sb = agb ? (o2 >> 1) : (o2 & 1u);
+        const u32 n_bs = agb ? (n2 & 1u) : (n2 >> 1), n_sb = agb ? (n2 >> 1) : (n2 & 1u);
+        const bool need_bs = o_bs != n_bs, need_sb = o_sb != n_sb;
+        u32 *wbs = rows + (size_t)big * stride32 + (small >> 5), *wsb = rows + (size_t)small * stride32 + (big >> 5);
+        const u32 bit_s = 1u << (small & 31u), bit_b = 1u << (big & 31u);
+        const u32 vbs = *wbs, vsb = *wsb;  // in flight with the list and the rows
+        res.sum_k += (u64)k * (u64)((need_bs ? 1 : 0) + (need_sb ? 1 : 0));
+        bool done = false;
+        const int s = k + 2;
+        if (s <= WAVE) {
+            const u32 Lv = load_list(p.nb, off, k, big, small, lane);
+            const u64 myH = build_local(rrows, stride32, Lv, s, lane);
+            Hs[lane] = myH;
+            wave_sync();
+            const u64 outB = Hs[k], outS = Hs[k + 1];
+            if ((u32)((outB >> (k + 1)) & 1ull) != o_bs || (u32)((outS >> k) & 1ull) != o_sb) res.status |= 1u;
+            const u64 inB = ballot((myH >> k) & 1ull), inS = ballot((myH >> (k + 1)) & 1ull);
+            const u64 nbm = ~(3ull << k);
+            Cls cbs, csb;  // classes around big->small and around small->big
+            cbs.P = csb.P = inB & inS & nbm;
+            cbs.S = csb.S = outB & outS & nbm;
+            cbs.M = outB & inS & nbm;
+            csb.M = outS & inB & nbm;
+            if ((!need_bs || extras_fit(cbs, s)) && (!need_sb || extras_fit(csb, s))) {
+                if (need_bs) eval_nodes<MAXT>(myH, Hp, cbs, k, tmax, n_bs ? +1 : -1, lane, delta);
+                if (need_sb) eval_nodes<MAXT>(myH, Hp, csb, k, tmax, n_sb ? +1 : -1, lane, delta);
+                if (lane == 0) {
+                    if (need_bs) *wbs = n_bs ? (vbs | bit_s) : (vbs & ~bit_s);
+                    if (need_sb) *wsb = n_sb ? (vsb | bit_b) : (vsb & ~bit_b);
+                }
                 wave_sync();
-            } else {
-                r = 0;
+                done = true;
             }
         }
-        if (r == 0) res.status |= 1u;  // the edge to count was not in the bitmap
-        if (!add) {
-            if (lane == 0) *word &= ~bit;
-            wave_sync();
+        if (!done) {
+            if (s > 64 * maxnw) { res.status |= 1u; continue; }
+            const Wide W = wide_carve(smem, maxnw);
+            for (int dir = 0; dir < 2; ++dir) {
+                if (!(dir == 0 ? need_bs : need_sb)) continue;
+                const bool add = (dir == 0 ? n_bs : n_sb) != 0u;
+                u32 *word = dir == 0 ? wbs : wsb;
+                const u32 bit = dir == 0 ? bit_s : bit_b;
+                if (add) {
+                    if (lane == 0) *word |= bit;
+                    wave_sync();
+                }
+                wide_zero_counts(W, lane);
+                if (!wide_edge(W, rows, stride32, p.nb, off, k, big, small, dir == 0 ? 1u : 0u, add ? +1 : -1, lane, tmax)) res.status |= 1u;
+                if (lane >= 2 && lane < 16 && lane - 1 <= tmax) res.wide_d += W.cnt[lane - 1];
+                wave_sync();
+                if (!add) {
+                    if (lane == 0) *word &= ~bit;
+                    wave_sync();
+                }
+            }
         }
-        res.sum_k += (u64)k;
     }
     return res;
 }
 
 // Put the bitmap back after a rejected clique move.
-__device__ __forceinline__ void clique_revert(u32 *rows, u32 stride32, const CliqueLds CL, int nchg, int lane)
+__device__ __forceinline__ void clique_revert(u32 *rows, u32 stride32, const CliqueLds CL, int npairs, int lane)
 {
-    for (int c = lane; c < nchg; c += WAVE) {
-        const u32 from = CL.chg[2 * c], tw = CL.chg[2 * c + 1];
-        const u32 to = tw & ~FCM_CHG_ADD;
-        u32 *word = rows + (size_t)from * stride32 + (to >> 5);
-        const u32 bit = 1u << (to & 31u);
-        if (tw & FCM_CHG_ADD) atomicAnd(word, ~bit); else atomicOr(word, bit);
+    for (int x = lane; x < npairs; x += WAVE) {
+        const u32 w0 = CL.chg[4 * x];
+        const u32 a = CL.d[w0 & 0xFFu], b = CL.d[(w0 >> 8) & 0xFFu];
+        const u32 o2 = (w0 >> 16) & 3u, ch = o2 ^ ((w0 >> 20) & 3u);
+        if (ch & 1u) {
+            u32 *word = rows + (size_t)a * stride32 + (b >> 5);
+            const u32 bit = 1u << (b & 31u);
+            if (o2 & 1u) atomicOr(word, bit); else atomicAnd(word, ~bit);
+        }
+        if (ch & 2u) {
+            u32 *word = rows + (size_t)b * stride32 + (a >> 5);
+            const u32 bit = 1u << (a & 31u);
+            if (o2 & 2u) atomicOr(word, bit); else atomicAnd(word, ~bit);
+        }
     }
     wave_sync();
 }
@@ -273,47 +343,28 @@ __device__ __forceinline__ void clique_revert(u32 *rows, u32 stride32, const Cli
 // After an accepted clique move: the reciprocal-pair slot list.  The i-th pair
 // (ascending pair id) that stopped being reciprocal hands its slot to the i-th
 // pair that became reciprocal (same rule in the oracle).  Returns a status bit.
-__device__ __forceinline__ u32 clique_update_slots(const FcmStepParams &p, u32 *dbl, u32 *slot_of, const CliqueLds CL, int n_d, int lane)
+__device__ __forceinline__ u32 clique_update_slots(u32 *dbl, u32 *slot_of, const CliqueLds CL, int npairs, int lane)
 {
-    const bool act = lane < n_d;
-    const u32 oldr = act ? CL.oldm[lane] : 0u, newr = act ? CL.newm[lane] : 0u;
-    u32 oldt = 0u, newt = 0u;  // transposes: bit j = row j has bit `lane`
-    for (int j = 0; j < n_d; ++j) {
-        oldt |= ((CL.oldm[j] >> lane) & 1u) << j;
-        newt |= ((CL.newm[j] >> lane) & 1u) << j;
+    u32 *lostv = CL.rowbuf, *gainv = CL.newm;  // 64 entries each (rowbuf+oldm, newm+p1: no longer needed)
+    int nl = 0, ng = 0;
+    wave_sync();
+    for (int base = 0; base < npairs; base += WAVE) {
+        const int x = base + lane;
+        const u32 w0 = x < npairs ? CL.chg[4 * x] : 0u;
+        const u32 o2 = (w0 >> 16) & 3u, n2 = (w0 >> 20) & 3u;
+        const bool lost = o2 == 3u && n2 != 3u, gained = n2 == 3u && o2 != 3u;
+        const u64 ml = ballot(lost), mg = ballot(gained);
+        const u64 below = (1ull << lane) - 1ull;
+        const int pl = nl + __popcll(ml & below), pg = ng + __popcll(mg & below);
+        nl += __popcll(ml);
+        ng += __popcll(mg);
+        if (nl > WAVE || ng > WAVE) return 128u;
+        if (lost) lostv[pl] = CL.chg[4 * x + 1];
+        if (gained) gainv[pg] = CL.chg[4 * x + 1];
     }
-    const u32 upper = act ? ~((2u << lane) - 1u) : 0u;  // pairs once: j > lane
-    const u32 was = oldr & oldt & upper, is = newr & newt & upper;
-    const u32 lost = was & ~is, gained = is & ~was;
-    const int nl_mine = __popc(lost), ng_mine = __popc(gained);
-    int incl = nl_mine, incg = ng_mine;
-#pragma unroll
-    for (int sft = 1; sft < WAVE; sft <<= 1) {
-        const int y = __shfl_up(incl, sft, WAVE), z = __shfl_up(incg, sft, WAVE);
-        if (lane >= sft) { incl += y; incg += z; }
-    }
-    const int nl = (int)rdlane((u32)incl, WAVE - 1), ng = (int)rdlane((u32)incg, WAVE - 1);
     if (nl != ng) return 64u;
     if (nl == 0) return 0u;
-    if (nl > WAVE || 2 * (u32)nl > 2 * p.chg_cap) return 128u;
-    // pair ids into LDS (the change list is no longer needed): lostv[0..nl), gainv[0..nl)
-    u32 *lostv = CL.chg, *gainv = CL.chg + nl;
     wave_sync();
-    {
-        int pl = incl - nl_mine, pg = incg - ng_mine;
-        for (u32 m = lost; m; m &= m - 1) lostv[pl++] = ((u32)lane << 8) | (u32)(__ffs((int)m) - 1);   // (i, j) packed
-        for (u32 m = gained; m; m &= m - 1) gainv[pg++] = ((u32)lane << 8) | (u32)(__ffs((int)m) - 1);
-    }
-    wave_sync();
-    // resolve (i,j) -> pair id, uniformly
-    for (int x = 0; x < 2 * nl; ++x) {
-        const u32 ij = CL.chg[x];
-        const u32 a = CL.d[ij >> 8], b = CL.d[ij & 0xFFu];
-        const u32 e = find_pair(p.etab, p.efirst, a > b ? a : b, a > b ? b : a, lane);
-        wave_sync();
-        if (lane == 0) CL.chg[x] = e;
-        wave_sync();
-    }
     // rank within each list (ascending id), then hand over the slots
     const u32 ml = lane < nl ? lostv[lane] : 0u, mg = lane < nl ? gainv[lane] : 0u;
     int rl = 0, rg = 0;
@@ -322,16 +373,14 @@ __device__ __forceinline__ u32 clique_update_slots(const FcmStepParams &p, u32 *
         rg += (gainv[y] < mg) ? 1 : 0;
     }
     wave_sync();
-    u32 *sortl = CL.rowbuf, *sortg = CL.rowbuf + 32;  // rowbuf + oldm: 64 slots
-    if (nl > 32) return 128u;
-    if (lane < nl) { sortl[rl] = ml; sortg[rg] = mg; }
+    if (lane < nl) gainv[rg] = mg;  // sorted in place (every lane holds its entry)
     wave_sync();
     if (lane < nl) {
-        const u32 le = sortl[lane], ge = sortg[lane];
-        const u32 slot = slot_of[le];
+        const u32 ge = gainv[rl];
+        const u32 slot = slot_of[ml];
         dbl[slot] = ge;
         slot_of[ge] = slot;
-        slot_of[le] = FCM_NOSLOT;
+        slot_of[ml] = FCM_NOSLOT;
     }
     wave_sync();
     return 0u;

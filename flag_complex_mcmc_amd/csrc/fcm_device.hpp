@@ -36,14 +36,17 @@ struct FcmStepParams {
     uint32_t n, stride32, U, D, dbl_stride, first_chain, nchains;
     // clique moves (reference src/lib.rs:214-290); all zero / null when their weights are 0
     const uint32_t *clq;       // maximal cliques of pr(G): bucket o-1 = cl_count[o-1] cliques of o vertices from clq[cl_base[o-1]]
+    const uint32_t *clq_pairs; // etab index of every vertex pair of every maximal clique: bucket o-1 from clq_pairs[clp_base[o-1]],
+                               // o(o-1)/2 per clique, positions (0,1),(0,2),..,(1,2),..
     const uint32_t *efirst;    // [n+1] first etab index whose `big` is v (etab is sorted by (big, small))
     uint32_t *slot_of;         // [n_chains][U] inverse of dbl: slot of a reciprocal pair, 0xFFFFFFFF otherwise
     uint64_t cl_base[FCM_DEV_MAX_COUNTS];
     uint64_t cl_count[FCM_DEV_MAX_COUNTS];
+    uint64_t clp_base[FCM_DEV_MAX_COUNTS];
     uint64_t cumo[FCM_DEV_MAX_COUNTS];   // clique_order_distribution as 2^32-scaled thresholds (sample.rs:87-88)
     uint64_t cum2;             // clique_permute if w0 < cum2, else clique_swap
     int32_t cl_orders;         // cliques_by_order.len()
-    uint32_t chg_cap;          // capacity of the change list in LDS (entries)
+    uint32_t chg_cap;          // u64 words of LDS for the changed-pair list of a clique move
     uint64_t *dbgbuf;          // [n_chains][8] cycle sums of a -DFCM_STAMP diagnostic build; unused otherwise
     int32_t ncounts;           // tracked count entries NC (<= 16)
     int32_t maxnw;             // mask words the largest local set needs: ceil((k_max+2)/64), 1..4

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             bool c_have_old = false;
             u32 c_slot = 0, c_newdbl = 0;
             bool is_dmove = false;
-            int clq_nchg = 0, clq_nd = 0;
+            int clq_npairs = 0;
             long long wide_d = 0;
 
             if (move == 0) {
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     status |= cr.status;
                     if (cr.nchg > 0) {
                         nonempty = true;
-                        clq_nchg = cr.nchg; clq_nd = cr.n_d;
+                        clq_npairs = cr.npairs;
                         wide_d = cr.wide_d;
                         sum_k += cr.sum_k;
                         n_changes += (u64)cr.nchg;
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     if (move >= 2) {
                         if constexpr (CLIQUE) {  // bits are already in place; hand over the reciprocal-pair slots
                             const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
-                            status |= clique_update_slots(p, dbl, slot_of, CL, clq_nd, lane);
+                            status |= clique_update_slots(dbl, slot_of, CL, clq_npairs, lane);
                         }
                     } else {
                         if (lane == 0) {
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 } else if (move >= 2) {
                     if constexpr (CLIQUE) {
                         const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
-                        clique_revert(rows, stride32, CL, clq_nchg, lane);
+                        clique_revert(rows, stride32, CL, clq_npairs, lane);
                     }
                 }
             }
