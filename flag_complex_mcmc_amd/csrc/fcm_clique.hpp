@@ -23,6 +23,11 @@
 
 #define FCM_CHG_ADD 0x80000000u
 #define FCM_NOSLOT 0xFFFFFFFFu
+#ifdef FCM_STAMP
+#define CLQ_STAMP(slot) do { const u64 _n = fcm_stamp(); sacc[slot] += _n - *stt; *stt = _n; } while (0)
+#else
+#define CLQ_STAMP(slot) do { } while (0)
+#endif
 
 struct CliqueLds {
     u32 *d;       // [32] vertices involved
@@ -94,7 +99,7 @@ struct CliqueResult {
 template <int MAXT>
 __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, const rsrc_t rrows, u64 *smem, const CliqueLds CL, int move,
                                                        u32 w1, u64 x64, u64 step, u32 gchain, u32 k0, u32 k1, int lane, int tmax,
-                                                       int maxnw, int (&delta)[MAXT + 1])
+                                                       int maxnw, int (&delta)[MAXT + 1], u64 *sacc, u64 *stt)
 {
     CliqueResult res = {0, 0, 0ull, 0ll, 0u};
     u64 *Hs = smem, *Hp = smem + WAVE;
@@ -167,6 +172,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
         }
         if (move == 2) break;  // clique_permute: one permutation of the whole clique
     }
+    CLQ_STAMP(1);                                                      // clique pick, d, permutations
     // ---- OLD: adjacency among d over the touched pairs
     const bool act = lane < n_d;
     const bool in_a = lane >= n_c && lane < n_c + n_a, in_b = lane >= n_c + n_a && lane < n_d;
@@ -225,6 +231,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
         }
     }
     wave_sync();
+    CLQ_STAMP(2);                                                      // OLD gather, NEW, pair list
     // ---- table entries of all changed pairs, in parallel
     {
         const u32 *ptab = p.clq_pairs + p.clp_base[oi];
@@ -250,6 +257,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
         if (ballot(bad)) { res.status = 1u; res.nchg = 0; res.npairs = 0; return res; }
     }
     wave_sync();
+    CLQ_STAMP(3);                                                      // pair ids + table entries
     // ---- apply one pair at a time, counting each directed change
     for (int x = 0; x < npairs; ++x) {
         const u32 w0 = CL.chg[4 * x], off = CL.chg[4 * x + 3];
@@ -273,15 +281,17 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
             const u64 myH = build_local(rrows, stride32, Lv, s, lane);
             Hs[lane] = myH;
             wave_sync();
-            const u64 outB = Hs[k], outS = Hs[k + 1];
-            if ((u32)((outB >> (k + 1)) & 1ull) != o_bs || (u32)((outS >> k) & 1ull) != o_sb) res.status |= 1u;
-            const u64 inB = ballot((myH >> k) & 1ull), inS = ballot((myH >> (k + 1)) & 1ull);
+            CLQ_STAMP(4);                                              // per pair: list + build
+            // in-masks: run on the transposed graph (see build_local)
+            const u64 inB = Hs[k], inS = Hs[k + 1];
+            if ((u32)((inS >> k) & 1ull) != o_bs || (u32)((inB >> (k + 1)) & 1ull) != o_sb) res.status |= 1u;
+            const u64 outB = ballot((myH >> k) & 1ull), outS = ballot((myH >> (k + 1)) & 1ull);
             const u64 nbm = ~(3ull << k);
-            Cls cbs, csb;  // classes around big->small and around small->big
-            cbs.P = csb.P = inB & inS & nbm;
-            cbs.S = csb.S = outB & outS & nbm;
-            cbs.M = outB & inS & nbm;
-            csb.M = outS & inB & nbm;
+            Cls cbs, csb;  // classes around big->small and around small->big, as classify(.., k+1, k) / (.., k, k+1) give them
+            cbs.P = csb.P = outB & outS & nbm;
+            cbs.S = csb.S = inB & inS & nbm;
+            cbs.M = inS & outB & nbm;
+            csb.M = inB & outS & nbm;
             if ((!need_bs || extras_fit(cbs, s)) && (!need_sb || extras_fit(csb, s))) {
                 if (need_bs) eval_nodes<MAXT>(myH, Hp, cbs, k, tmax, n_bs ? +1 : -1, lane, delta);
                 if (need_sb) eval_nodes<MAXT>(myH, Hp, csb, k, tmax, n_sb ? +1 : -1, lane, delta);
@@ -292,6 +302,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
                 wave_sync();
                 done = true;
             }
+            CLQ_STAMP(5);                                              // per pair: evaluations + stores
         }
         if (!done) {
             if (s > 64 * maxnw) { res.status |= 1u; continue; }

@@ -138,10 +138,19 @@ __device__ __forceinline__ u64 fcm_stamp()
 // Fast evaluator: local sets of <= 64 vertices, one u64 mask per vertex
 // ===========================================================================
 
-// Induced out-adjacency of the local vertex set.  Lane j (< s) holds local
-// vertex Lv.  Returns this lane's out-mask over local indices 0..s-1.  One
-// dword per lane per row: bit L[j] of row L[i].  Rows are 128-B multiples, so
-// one row-read is one or few cache lines, shared by the 64 lanes.
+// Induced adjacency of the local vertex set, as IN-masks.  Lane j (< s) holds
+// local vertex Lv = L[j] and gets the mask { i : L[i] -> L[j] } over local
+// indices 0..s-1.  One dword per lane per row: the one with bit L[j] of row
+// L[i]; the lane keeps its own bit, so a row costs v_readlane + buffer_load +
+// v_bfe + v_lshl_or and no cross-lane traffic.  (Out-masks would need a ballot
+// and two v_writelane per row.)  Rows are 128-B multiples, so one row-read is
+// one or few cache lines, shared by the 64 lanes.
+//
+// The evaluator below is written for out-masks; it is run on these in-masks,
+// i.e. on the transposed graph, where the simplices through u->v are the
+// simplices through v->u (same sets, orders reversed, classes P and S
+// swapped).  Callers therefore hand classify() the endpoints the other way
+// round, and read "x -> y is present" as bit x of the mask of y.
 #ifndef FCM_HB
 #define FCM_HB 24  // rows in flight per batch (16: -2%, 32: -4% on config 3)
 #endif
@@ -152,17 +161,6 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rows_rsrc(const u32 *rows, u64 bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void *)rows, 0, (int)(u32)bytes, 0x00020000);
-}
-// lane L (a compile-time constant) of (lo, hi) := the wave-uniform 64-bit value m.  The lane
-// select is an inline constant, so the two SGPR halves are the only scalar operands.
-// s_nop 1: on gfx940+ a VALU write of an SGPR/VCC (the v_cmp that made m) needs two wait states
-// before a VALU reads it; hipcc pads that itself, but not across an asm boundary
-// (cdna_hip_programming.md 5.7).  Without it the masks come out wrong.
-template <int L>
-__device__ __forceinline__ void wrlane64c(u64 m, u32 &lo, u32 &hi)
-{
-    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-        : "+v"(lo), "+v"(hi) : "s"((u32)m), "s"((u32)(m >> 32)), "n"(L));
 }
 
 // rows I0 .. I0+N-1 of the local adjacency (those below s when GUARDED): issue the reads ...
@@ -176,73 +174,74 @@ __device__ __forceinline__ void build_issue(const rsrc_t rsrc, u32 voff, u32 rof
             w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, I0 + q), 0);
     }
 }
-// ... and turn them into masks: the v_cmp result is the ballot, v_writelane drops it into lane I0+q
-template <int I0, int N, bool GUARDED, int Q = 0>
-__device__ __forceinline__ void build_consume(const u32 (&w)[N], u32 bmask, int s, u32 &hlo, u32 &hhi)
+// ... and keep this lane's bit of each: bit I0+q of the mask.  A slot that was not read holds 0.
+template <int I0, int N, int Q = 0>
+__device__ __forceinline__ void build_consume(const u32 (&w)[N], u32 bpos, u32 &hlo, u32 &hhi)
 {
     if constexpr (Q < N) {
-        if (!GUARDED || I0 + Q < s) wrlane64c<I0 + Q>(ballot((w[Q] & bmask) != 0u), hlo, hhi);
-        build_consume<I0, N, GUARDED, Q + 1>(w, bmask, s, hlo, hhi);
+        constexpr int R = I0 + Q;
+        const u32 bit = __builtin_amdgcn_ubfe(w[Q], bpos, 1u);
+        if constexpr (R < 32) hlo |= bit << R; else hhi |= bit << (R - 32);
+        build_consume<I0, N, Q + 1>(w, bpos, hlo, hhi);
     }
 }
 
-// A guarded batch of N slots costs a compare and a branch per slot, twice (issue, consume), so
-// it is instantiated in steps of four and the smallest size that holds `cnt` rows is used.
+// A guarded batch of N slots costs a compare and a branch per slot at issue, so it is
+// instantiated in steps of four and the smallest size that holds `cnt` rows is used.
 template <int I0, int N>
-__device__ __forceinline__ void build_tail(const rsrc_t rsrc, u32 voff, u32 bmask, u32 roff, int s, u32 &hlo, u32 &hhi)
+__device__ __forceinline__ void build_tail(const rsrc_t rsrc, u32 voff, u32 bpos, u32 roff, int s, u32 &hlo, u32 &hhi)
 {
     u32 w[N];
     build_issue<I0, N, true>(rsrc, voff, roff, s, w);
-    build_consume<I0, N, true>(w, bmask, s, hlo, hhi);
+    build_consume<I0, N>(w, bpos, hlo, hhi);
 }
 // the same with the unguarded batch `wa` (rows 0..FCM_HB-1) consumed between issue and consume
 // of the tail, so that all reads are in flight together
 template <int N>
-__device__ __forceinline__ void build_second(const rsrc_t rsrc, u32 voff, u32 bmask, u32 roff, int s, const u32 (&wa)[FCM_HB],
+__device__ __forceinline__ void build_second(const rsrc_t rsrc, u32 voff, u32 bpos, u32 roff, int s, const u32 (&wa)[FCM_HB],
                                              u32 &hlo, u32 &hhi)
 {
     u32 wb[N];
     build_issue<FCM_HB, N, true>(rsrc, voff, roff, s, wb);
-    build_consume<0, FCM_HB, false>(wa, bmask, s, hlo, hhi);
-    build_consume<FCM_HB, N, true>(wb, bmask, s, hlo, hhi);
+    build_consume<0, FCM_HB>(wa, bpos, hlo, hhi);
+    build_consume<FCM_HB, N>(wb, bpos, hlo, hhi);
 }
 
-// Every row index below is a compile-time constant (a local set has at most 64 rows), so the
-// per-row cost is v_readlane + buffer_load + v_and + v_cmp + 2 v_writelane and nothing else.
+// Every row index below is a compile-time constant (a local set has at most 64 rows).
 __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 Lv, int s, int lane)
 {
     static_assert(FCM_HB == 24, "the tiers below are written for 24-row batches");
     const bool act = lane < s;
     const u32 voff = act ? (Lv >> 5) * 4u : 0u;          // byte offset of this lane's dword inside a row
-    const u32 bmask = act ? (1u << (Lv & 31u)) : 0u;     // inactive lanes never set a bit
+    const u32 bpos = Lv & 31u;                           // this lane's bit inside that dword
     const u32 roff = Lv * (stride32 * 4u);               // byte offset of row Lv; read back per row by v_readlane
-    u32 hlo = 0u, hhi = 0u;                              // this lane's row, written by v_writelane
+    u32 hlo = 0u, hhi = 0u;
     if (s <= 24) {                                       // one guarded batch
-        if (s <= 4) build_tail<0, 4>(rsrc, voff, bmask, roff, s, hlo, hhi);
-        else if (s <= 8) build_tail<0, 8>(rsrc, voff, bmask, roff, s, hlo, hhi);
-        else if (s <= 12) build_tail<0, 12>(rsrc, voff, bmask, roff, s, hlo, hhi);
-        else if (s <= 16) build_tail<0, 16>(rsrc, voff, bmask, roff, s, hlo, hhi);
-        else if (s <= 20) build_tail<0, 20>(rsrc, voff, bmask, roff, s, hlo, hhi);
-        else build_tail<0, 24>(rsrc, voff, bmask, roff, s, hlo, hhi);
+        if (s <= 4) build_tail<0, 4>(rsrc, voff, bpos, roff, s, hlo, hhi);
+        else if (s <= 8) build_tail<0, 8>(rsrc, voff, bpos, roff, s, hlo, hhi);
+        else if (s <= 12) build_tail<0, 12>(rsrc, voff, bpos, roff, s, hlo, hhi);
+        else if (s <= 16) build_tail<0, 16>(rsrc, voff, bpos, roff, s, hlo, hhi);
+        else if (s <= 20) build_tail<0, 20>(rsrc, voff, bpos, roff, s, hlo, hhi);
+        else build_tail<0, 24>(rsrc, voff, bpos, roff, s, hlo, hhi);
     } else {
         // 24 unguarded rows plus a guarded tail, and the reads of BOTH are issued before either is
         // consumed: a local set of up to 48 vertices costs one memory round trip, not two.
         u32 wa[FCM_HB];
         build_issue<0, FCM_HB, false>(rsrc, voff, roff, s, wa);
-        if (s <= 28) build_second<4>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
-        else if (s <= 32) build_second<8>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
-        else if (s <= 36) build_second<12>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
-        else if (s <= 40) build_second<16>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
-        else if (s <= 44) build_second<20>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
+        if (s <= 28) build_second<4>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
+        else if (s <= 32) build_second<8>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
+        else if (s <= 36) build_second<12>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
+        else if (s <= 40) build_second<16>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
+        else if (s <= 44) build_second<20>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
         else {
-            build_second<24>(rsrc, voff, bmask, roff, s, wa, hlo, hhi);
+            build_second<24>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
             if (s > 48) {                                // rows 48..63
-                if (s <= 56) build_tail<48, 8>(rsrc, voff, bmask, roff, s, hlo, hhi);
-                else build_tail<48, 16>(rsrc, voff, bmask, roff, s, hlo, hhi);
+                if (s <= 56) build_tail<48, 8>(rsrc, voff, bpos, roff, s, hlo, hhi);
+                else build_tail<48, 16>(rsrc, voff, bpos, roff, s, hlo, hhi);
             }
         }
     }
-    return (u64)hlo | ((u64)hhi << 32);  // lanes >= s were never written: 0
+    return act ? ((u64)hlo | ((u64)hhi << 32)) : 0ull;   // lanes >= s read dword 0 of every row: discard
 }
 
 // ---------------------------------------------------------------------------
@@ -266,7 +265,8 @@ __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 
 
 struct Cls { u64 P, M, S; };
 
-// classes relative to u->v (local indices iu, iv); the edge must be present
+// classes relative to u->v (local indices iu, iv) in the graph whose out-masks are myH / Hs.
+// With the in-masks build_local makes, pass (index of v, index of u) for an edge u->v of G.
 __device__ __forceinline__ Cls classify(u64 myH, const u64 *Hs, int iu, int iv)
 {
     const u64 outU = Hs[iu], outV = Hs[iv];
@@ -376,14 +376,14 @@ __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv
     u64 myH = build_local(rows, stride32, Lv, s, lane);
     Hs[lane] = myH;
     wave_sync();
-    const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
+    const u32 ab = (u32)((Hs[k + 1] >> k) & 1ull), ba = (u32)((Hs[k] >> (k + 1)) & 1ull);  // big->small, small->big
     if (ab == ba) return ab ? 0 : -1;
     const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;  // u->v present
-    Cls c = classify(myH, Hs, iu, iv);
+    Cls c = classify(myH, Hs, iv, iu);
     // after the flip P and S are the same sets, M becomes {v->w, w->u}
     Cls c2;
     c2.P = c.P; c2.S = c.S;
-    c2.M = Hs[iv] & ballot((myH >> iu) & 1ull) & ~(3ull << k);
+    c2.M = Hs[iu] & ballot((myH >> iv) & 1ull) & ~(3ull << k);
     if (!extras_fit(c, s) || !extras_fit(c2, s)) return FCM_NEEDS_WIDE;
     eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
     eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta);
@@ -401,9 +401,9 @@ __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv,
     const u64 myH = build_local(rows, stride32, Lv, s, lane);
     Hs[lane] = myH;
     wave_sync();
-    const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
+    const u32 ab = (u32)((Hs[k + 1] >> k) & 1ull), ba = (u32)((Hs[k] >> (k + 1)) & 1ull);
     const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
-    const Cls c = classify(myH, Hs, iu, iv);
+    const Cls c = classify(myH, Hs, iv, iu);
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
     eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
     return (ab & ba) ? 1 : 0;
@@ -411,7 +411,7 @@ __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv,
 
 // double_edge_move step 2: on the graph without dfrom->dto, add the reverse of
 // the single edge of (big,small) and add the simplices through it.  fwd=1
-// means big->small is the existing direction.  `myH` = the lane's raw mask of
+// means big->small is the existing direction.  `myH` = the lane's raw in-mask of
 // the local set Lv (k vertices of K, then big, small), built by the caller.
 template <int MAXT>
 __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u32 dfrom, u32 dto, u64 *Hs, u64 *Hp, int lane,
@@ -422,13 +422,13 @@ __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u
     const u64 mf = ballot(act && Lv == dfrom), mt = ballot(act && Lv == dto);
     if (mf && mt) {  // the pending removal, if both its endpoints are local
         const int fi = __ffsll((long long)mf) - 1, ti = __ffsll((long long)mt) - 1;
-        if (lane == fi) myH &= ~(1ull << ti);
+        if (lane == ti) myH &= ~(1ull << fi);
     }
     const int ia = fwd ? k : k + 1, ib = fwd ? k + 1 : k;  // a->b exists, add b->a
-    if (lane == ib) myH |= (1ull << ia);
+    if (lane == ia) myH |= (1ull << ib);
     Hs[lane] = myH;
     wave_sync();
-    const Cls c = classify(myH, Hs, ib, ia);
+    const Cls c = classify(myH, Hs, ia, ib);
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
     eval_nodes<MAXT>(myH, Hp, c, k, tmax, +1, lane, delta);
     return 1;
@@ -818,13 +818,13 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             FCM_STAMP_AT(2);                           // flip: build
                             Hs[lane] = myH;
                             wave_sync();
-                            const u32 ab = (u32)((Hs[k] >> (k + 1)) & 1ull), ba = (u32)((Hs[k + 1] >> k) & 1ull);
+                            const u32 ab = (u32)((Hs[k + 1] >> k) & 1ull), ba = (u32)((Hs[k] >> (k + 1)) & 1ull);
                             if (ab == ba) res = ab ? 0 : -1;
                             else {
                                 const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;
-                                Cls c = classify(myH, Hs, iu, iv);
+                                Cls c = classify(myH, Hs, iv, iu);
                                 Cls c2; c2.P = c.P; c2.S = c.S;
-                                c2.M = Hs[iv] & ballot((myH >> iu) & 1ull) & ~(3ull << k);
+                                c2.M = Hs[iu] & ballot((myH >> iv) & 1ull) & ~(3ull << k);
                                 if (!extras_fit(c, k + 2) || !extras_fit(c2, k + 2)) res = FCM_NEEDS_WIDE;
                                 else {
                                     eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             if (ck + 2 <= WAVE) {
                                 Lv2 = load_list(nb, ce.nb_off, ck, ce.big, ce.small, lane);
                                 myH2 = build_local(rrows, stride32, Lv2, ck + 2, lane);
-                                const u32 f = (u32)(rdlane64(myH2, ck) >> (ck + 1)) & 1u, bwd = (u32)(rdlane64(myH2, ck + 1) >> ck) & 1u;
+                                const u32 f = (u32)(rdlane64(myH2, ck + 1) >> ck) & 1u, bwd = (u32)(rdlane64(myH2, ck) >> (ck + 1)) & 1u;
                                 if (!(f | bwd)) status |= 1u;
                                 found = (f ^ bwd) != 0u;
                                 rfwd = f;
@@ -971,7 +971,12 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 // ---- clique_permute / clique_swap (src/lib.rs:214-290) -------
                 if constexpr (CLIQUE) {
                     const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
-                    const CliqueResult cr = clique_propose<MAXT>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta);
+#ifdef FCM_STAMP
+                    u64 *clq_sacc = stamp_acc, *clq_stt = &stamp_t;
+#else
+                    u64 *clq_sacc = nullptr, *clq_stt = nullptr;
+#endif
+                    const CliqueResult cr = clique_propose<MAXT>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta, clq_sacc, clq_stt);
                     status |= cr.status;
                     if (cr.nchg > 0) {
                         nonempty = true;

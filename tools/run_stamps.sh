@@ -5,5 +5,5 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT/flag_complex_mcmc_amd/csrc
 cp ../libfcm.so /tmp/libfcm_product.so
 make -s clean >/dev/null; make -s -j8 EXTRA=-DFCM_STAMP >/dev/null
-cd $ROOT && python tools/run_stamps.py
+cd $ROOT && python tools/run_stamps.py $1
 cp /tmp/libfcm_product.so flag_complex_mcmc_amd/libfcm.so
