@@ -110,18 +110,23 @@ __global__ __launch_bounds__(256) void fcm_broadcast_rows_kernel(uint4 *__restri
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
+typedef int (*fcm_step_launcher)(const FcmStepParams *, void *);
+#define FCM_DECL_STEP(tag) int fcm_launch_step_##tag##_0(const FcmStepParams *, void *); int fcm_launch_step_##tag##_1(const FcmStepParams *, void *);
 extern "C" {
-int fcm_launch_step_6_0(const FcmStepParams *, void *);
-int fcm_launch_step_14_0(const FcmStepParams *, void *);
-int fcm_launch_step_6_1(const FcmStepParams *, void *);
-int fcm_launch_step_14_1(const FcmStepParams *, void *);
+FCM_DECL_STEP(6) FCM_DECL_STEP(14) FCM_DECL_STEP(x2) FCM_DECL_STEP(x3) FCM_DECL_STEP(x4) FCM_DECL_STEP(x5) FCM_DECL_STEP(x6)
 }
 
-// maxt: 6 (<= 8 count entries) or 14; clique: kernel variant with the clique moves
-extern "C" int fcm_launch_step(const FcmStepParams *p, int maxt, int clique, void *stream)
+// tmax = tracked depth (count entries - 2); clique: kernel variant with the clique moves
+extern "C" int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, void *stream)
 {
-    if (clique) return maxt <= 6 ? fcm_launch_step_6_1(p, stream) : fcm_launch_step_14_1(p, stream);
-    return maxt <= 6 ? fcm_launch_step_6_0(p, stream) : fcm_launch_step_14_0(p, stream);
+    static const fcm_step_launcher exact[5][2] = {
+        {fcm_launch_step_x2_0, fcm_launch_step_x2_1}, {fcm_launch_step_x3_0, fcm_launch_step_x3_1},
+        {fcm_launch_step_x4_0, fcm_launch_step_x4_1}, {fcm_launch_step_x5_0, fcm_launch_step_x5_1},
+        {fcm_launch_step_x6_0, fcm_launch_step_x6_1}};
+    const int c = clique ? 1 : 0;
+    if (tmax >= 2 && tmax <= 6) return exact[tmax - 2][c](p, stream);
+    if (tmax <= 6) return c ? fcm_launch_step_6_1(p, stream) : fcm_launch_step_6_0(p, stream);
+    return c ? fcm_launch_step_14_1(p, stream) : fcm_launch_step_14_0(p, stream);
 }
 
 extern "C" int fcm_launch_count(const FcmCountParams *p, void *stream)

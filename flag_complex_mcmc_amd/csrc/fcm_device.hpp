@@ -65,7 +65,7 @@ struct FcmCountParams {
 extern "C" {
 #endif
 // launchers implemented in fcm_kernels.hip; `stream` is a hipStream_t
-int fcm_launch_step(const FcmStepParams *p, int maxt, int clique, void *stream);
+int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, void *stream);
 int fcm_launch_count(const FcmCountParams *p, void *stream);
 int fcm_launch_broadcast_rows(uint32_t *rows, const uint32_t *base, uint64_t words_per_chain, uint32_t nchains, void *stream);
 #ifdef __cplusplus

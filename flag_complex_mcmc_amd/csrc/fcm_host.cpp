@@ -751,7 +751,7 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     if (cfg->dim_cap > 0 && cfg->dim_cap + 1 < want) { nc = cfg->dim_cap + 1; lossless = false; }
     if (nc > FCM_MAX_COUNTS) return fail(FCM_ERR_UNSUPPORTED, "needs %d count entries, this build tracks at most %d; pass a dim_cap", nc, FCM_MAX_COUNTS);
     nc = std::max(nc, 2);
-    s->maxt_variant = (nc - 2 <= 6) ? 6 : 14;
+    s->maxt_variant = nc - 2;   // tracked depth; fcm_launch_step picks the kernel variant
 
     // --- device buffers -----------------------------------------------------
     const uint64_t rows_per_chain = (uint64_t)g->n * g->stride32;

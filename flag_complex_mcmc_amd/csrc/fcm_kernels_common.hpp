@@ -701,7 +701,7 @@ __device__ __forceinline__ void wide_add(const Wide W, const u32 *rows, u32 stri
 // MINW = minimum waves per SIMD the register allocator must leave room for.
 // CLIQUE = true adds the clique moves (fcm_clique.hpp); the simple-move kernel
 // is compiled without them and keeps its register allocation.
-template <int MAXT, int MINW, bool CLIQUE>
+template <int MAXT, int MINW, bool CLIQUE, bool EXACT>
 __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];  // fcm_lds_words(p.maxnw) words
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     const u32 *nb = p.nb;
 
     const int NC = p.ncounts;
-    const int tmax = NC - 2;
+    const int tmax = EXACT ? MAXT : NC - 2;  // EXACT: the host picked the variant with MAXT == NC - 2
     const bool cl = lane < NC;
     // lane d holds count[d] and its bounds (zero-padded, src/util.rs:53-57)
     u64 cnt = cl ? cnt_g[lane] : 0ull;

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import flag_complex_mcmc_amd as fcm
 from flag_complex_mcmc_amd import _ffi
-n, chains, props = 1000, 4096, 512
+n, chains, props = 1000, int(os.environ.get("FCM_STAMP_CHAINS", "4096")), 512
 CLIQUE = len(sys.argv) > 1 and sys.argv[1] == "clique"   # clique moves only: slots 1..5 then mean the clique phases
 e = fcm.graphs.random_with_p(n, 0.10, 0)
 if CLIQUE:
