@@ -98,6 +98,17 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
     return __builtin_amdgcn_readlane(v, 63);
 }
+// the same steps, keeping every lane's inclusive prefix sum
+__device__ __forceinline__ int wave_scan_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
 
 // The workgroup is ONE wave.  Vector-memory and LDS instructions of a wave are
 // issued and performed in program order, so data one lane wrote is visible to
@@ -309,6 +320,45 @@ __device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sig
     }
 }
 
+// The walk over the split graph in Hp (lane x = node x, `row` = its children).  One lane per
+// node would leave the lanes in lockstep through nested child loops whose trip counts are the
+// maxima over the wave: a handful of children per node, most lanes idle.  Instead the arcs
+// (node, child) -- about as many as there are lanes -- are listed in LDS and dealt out one per
+// lane, so that the first loop level disappears and only the short deeper loops remain per lane.
+// The list sits behind Hp (FCM_PAIR_CAP 16-bit entries).
+#define FCM_PAIR_CAP 256
+template <int MAXT>
+__device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1])
+{
+    u32 dummy = 0;
+    if constexpr (MAXT >= 3) {
+        if (tmax >= 3) {
+            const int nch = __popcll(row);
+            const int incl = wave_scan_i32(nch);
+            const int tp = __builtin_amdgcn_readlane(incl, 63);
+            if (tp <= FCM_PAIR_CAP) {
+                delta[2] += sign * nch;
+                if (tp == 0) return;
+                unsigned short *list = (unsigned short *)(Hp + WAVE);
+                int pos = incl - nch;
+                for (u64 c = row; c; c &= c - 1) list[pos++] = (unsigned short)((u32)lane | ((u32)(__ffsll((long long)c) - 1) << 8));
+                wave_sync();
+                for (int base = 0; base < tp; base += WAVE) {
+                    const int pi = base + lane;
+                    u64 nc = 0ull;
+                    if (pi < tp) {
+                        const u32 e = list[pi];
+                        nc = Hp[e & 0xFFu] & Hp[e >> 8];
+                    }
+                    if (nc) visit<2, MAXT, false>(nc, Hp, tmax, sign, delta, dummy);
+                }
+                return;
+            }
+        }
+    }
+    if (row) visit<1, MAXT, false>(row, Hp, tmax, sign, delta, dummy);
+}
+
 // E(G, u->v): builds the split graph for classes `c` into Hp and counts.
 // myH / Hs hold the raw local adjacency; local indices k, k+1 are the edge's
 // endpoints.  Requires extras_fit(c, k+2).
@@ -354,8 +404,7 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
     Hp[lane] = row;
     wave_sync();
     if (tmax >= 1 && cls != 3) delta[1] += sign;
-    u32 dummy = 0;
-    if (row) visit<1, MAXT, false>(row, Hp, tmax, sign, delta, dummy);
+    walk_nodes<MAXT>(row, Hp, tmax, sign, lane, delta);
     wave_sync();
 }
 
@@ -459,7 +508,7 @@ struct Wide {
 // u64 words of dynamic LDS a workgroup needs for local sets of up to 64*NW vertices
 __host__ __device__ inline unsigned fcm_lds_words(int NW)
 {
-    if (NW <= 1) return 2u * 64u;  // Hs + Hp
+    if (NW <= 1) return 3u * 64u;  // Hs + Hp + the arc list of walk_nodes
     return 64u * NW * NW + 12u + FCM_WIDE_LEVELS * 8u + 16u + FCM_WIDE_LEVELS + 32u * NW;
 }
 __device__ __forceinline__ Wide wide_carve(u64 *smem, int NW)
