@@ -102,7 +102,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
                                                        int maxnw, int (&delta)[MAXT + 1], u64 *sacc, u64 *stt)
 {
     CliqueResult res = {0, 0, 0ull, 0ll, 0u};
-    u64 *Hs = smem, *Hp = smem + WAVE;
+    u64 *Hp = smem + WAVE;
     const u32 stride32 = p.stride32;
     // ---- clique_order_distribution.sample, cliques.choose (src/lib.rs:215-216, 235-237)
     int oi = 0;
@@ -279,11 +279,9 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
         if (s <= WAVE) {
             const u32 Lv = load_list(p.nb, off, k, big, small, lane);
             const u64 myH = build_local(rrows, stride32, Lv, s, lane);
-            Hs[lane] = myH;
-            wave_sync();
             CLQ_STAMP(4);                                              // per pair: list + build
             // in-masks: run on the transposed graph (see build_local)
-            const u64 inB = Hs[k], inS = Hs[k + 1];
+            const u64 inB = rdlane64(myH, k), inS = rdlane64(myH, k + 1);
             if ((u32)((inS >> k) & 1ull) != o_bs || (u32)((inB >> (k + 1)) & 1ull) != o_sb) res.status |= 1u;
             const u64 outB = ballot((myH >> k) & 1ull), outS = ballot((myH >> (k + 1)) & 1ull);
             const u64 nbm = ~(3ull << k);

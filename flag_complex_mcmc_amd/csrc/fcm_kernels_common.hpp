@@ -140,9 +140,11 @@ __device__ __forceinline__ u64 fcm_stamp()
 }
 #define FCM_STAMP_DECL u64 stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 stamp_t = fcm_stamp();
 #define FCM_STAMP_AT(slot) do { const u64 _n = fcm_stamp(); stamp_acc[slot] += _n - stamp_t; stamp_t = _n; } while (0)
+#define FCM_STAMP_PTR(slot) do { if (sacc) { const u64 _n = fcm_stamp(); sacc[slot] += _n - *stt; *stt = _n; } } while (0)
 #else
 #define FCM_STAMP_DECL
 #define FCM_STAMP_AT(slot) do { } while (0)
+#define FCM_STAMP_PTR(slot) do { } while (0)
 #endif
 
 // ===========================================================================
@@ -276,11 +278,11 @@ __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 
 
 struct Cls { u64 P, M, S; };
 
-// classes relative to u->v (local indices iu, iv) in the graph whose out-masks are myH / Hs.
+// classes relative to u->v (local indices iu, iv) in the graph whose out-masks are myH (one per lane).
 // With the in-masks build_local makes, pass (index of v, index of u) for an edge u->v of G.
-__device__ __forceinline__ Cls classify(u64 myH, const u64 *Hs, int iu, int iv)
+__device__ __forceinline__ Cls classify(u64 myH, int iu, int iv)
 {
-    const u64 outU = Hs[iu], outV = Hs[iv];
+    const u64 outU = rdlane64(myH, iu), outV = rdlane64(myH, iv);  // v_readlane with an SGPR lane index: no LDS round trip
     const u64 inU = ballot((myH >> iu) & 1ull), inV = ballot((myH >> iv) & 1ull);
     const u64 nbm = ~((1ull << iu) | (1ull << iv));
     Cls c;
@@ -328,7 +330,8 @@ __device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sig
 // The list sits behind Hp (FCM_PAIR_CAP 16-bit entries).
 #define FCM_PAIR_CAP 256
 template <int MAXT>
-__device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1])
+__device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1],
+                                           u64 *sacc = nullptr, u64 *stt = nullptr)
 {
     u32 dummy = 0;
     if constexpr (MAXT >= 3) {
@@ -343,6 +346,7 @@ __device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int
                 int pos = incl - nch;
                 for (u64 c = row; c; c &= c - 1) list[pos++] = (unsigned short)((u32)lane | ((u32)(__ffsll((long long)c) - 1) << 8));
                 wave_sync();
+                FCM_STAMP_PTR(4);                                      // (flips-only diagnostic) arc scan + scatter
                 for (int base = 0; base < tp; base += WAVE) {
                     const int pi = base + lane;
                     u64 nc = 0ull;
@@ -352,6 +356,7 @@ __device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int
                     }
                     if (nc) visit<2, MAXT, false>(nc, Hp, tmax, sign, delta, dummy);
                 }
+                FCM_STAMP_PTR(5);                                      // (flips-only diagnostic) arcs and deeper levels
                 return;
             }
         }
@@ -360,11 +365,11 @@ __device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int
 }
 
 // E(G, u->v): builds the split graph for classes `c` into Hp and counts.
-// myH / Hs hold the raw local adjacency; local indices k, k+1 are the edge's
+// myH holds the raw local adjacency; local indices k, k+1 are the edge's
 // endpoints.  Requires extras_fit(c, k+2).
 template <int MAXT>
 __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k, int tmax, int sign, int lane,
-                                           int (&delta)[MAXT + 1])
+                                           int (&delta)[MAXT + 1], u64 *sacc = nullptr, u64 *stt = nullptr)
 {
     const int s = k + 2;
     const u64 uv = 3ull << k;
@@ -403,15 +408,16 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
     row &= cls == 0 ? G0 : (cls == 1 ? G1 : (cls == 2 ? G2 : 0ull));
     Hp[lane] = row;
     wave_sync();
+    FCM_STAMP_PTR(3);                                                  // (flips-only diagnostic) classes, seating, split rows
     if (tmax >= 1 && cls != 3) delta[1] += sign;
-    walk_nodes<MAXT>(row, Hp, tmax, sign, lane, delta);
+    walk_nodes<MAXT>(row, Hp, tmax, sign, lane, delta, sacc, stt);
     wave_sync();
 }
 
 // ---- the three evaluations a simple move is made of (fast path) -------------
 // Lv = the local vertex list (K, then big, small: lane k = big, lane k+1 = small),
-// loaded by the caller.  Hs = raw masks, Hp = split
-// graph (both 64 u64 in LDS).  Each returns FCM_NEEDS_WIDE when the extras do
+// loaded by the caller.  The raw masks stay in registers; Hp = split
+// graph (64 u64 in LDS).  Each returns FCM_NEEDS_WIDE when the extras do
 // not fit; the caller then zeroes delta and redoes the proposal on the wide path.
 
 // single_edge_flip on undirected edge (big,small): returns 0 if the pair is
@@ -419,20 +425,19 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
 __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
-                                         u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
+                                         u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
     u64 myH = build_local(rows, stride32, Lv, s, lane);
-    Hs[lane] = myH;
-    wave_sync();
-    const u32 ab = (u32)((Hs[k + 1] >> k) & 1ull), ba = (u32)((Hs[k] >> (k + 1)) & 1ull);  // big->small, small->big
+    const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
+    const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);  // big->small, small->big
     if (ab == ba) return ab ? 0 : -1;
     const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;  // u->v present
-    Cls c = classify(myH, Hs, iv, iu);
+    Cls c = classify(myH, iv, iu);
     // after the flip P and S are the same sets, M becomes {v->w, w->u}
     Cls c2;
     c2.P = c.P; c2.S = c.S;
-    c2.M = Hs[iu] & ballot((myH >> iv) & 1ull) & ~(3ull << k);
+    c2.M = (ab ? hk : hk1) & ballot((myH >> iv) & 1ull) & ~(3ull << k);
     if (!extras_fit(c, s) || !extras_fit(c2, s)) return FCM_NEEDS_WIDE;
     eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
     eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta);
@@ -444,15 +449,13 @@ __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
 __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
-                                        u32 coin, u64 *Hs, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
+                                        u32 coin, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
     const u64 myH = build_local(rows, stride32, Lv, s, lane);
-    Hs[lane] = myH;
-    wave_sync();
-    const u32 ab = (u32)((Hs[k + 1] >> k) & 1ull), ba = (u32)((Hs[k] >> (k + 1)) & 1ull);
+    const u32 ab = (u32)((rdlane64(myH, k + 1) >> k) & 1ull), ba = (u32)((rdlane64(myH, k) >> (k + 1)) & 1ull);
     const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
-    const Cls c = classify(myH, Hs, iv, iu);
+    const Cls c = classify(myH, iv, iu);
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
     eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
     return (ab & ba) ? 1 : 0;
@@ -463,7 +466,7 @@ __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv,
 // means big->small is the existing direction.  `myH` = the lane's raw in-mask of
 // the local set Lv (k vertices of K, then big, small), built by the caller.
 template <int MAXT>
-__device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u32 dfrom, u32 dto, u64 *Hs, u64 *Hp, int lane,
+__device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u32 dfrom, u32 dto, u64 *Hp, int lane,
                                               int tmax, int (&delta)[MAXT + 1])
 {
     const int s = k + 2;
@@ -475,9 +478,7 @@ __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u
     }
     const int ia = fwd ? k : k + 1, ib = fwd ? k + 1 : k;  // a->b exists, add b->a
     if (lane == ia) myH |= (1ull << ib);
-    Hs[lane] = myH;
-    wave_sync();
-    const Cls c = classify(myH, Hs, ia, ib);
+    const Cls c = classify(myH, ia, ib);
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
     eval_nodes<MAXT>(myH, Hp, c, k, tmax, +1, lane, delta);
     return 1;
@@ -508,7 +509,7 @@ struct Wide {
 // u64 words of dynamic LDS a workgroup needs for local sets of up to 64*NW vertices
 __host__ __device__ inline unsigned fcm_lds_words(int NW)
 {
-    if (NW <= 1) return 3u * 64u;  // Hs + Hp + the arc list of walk_nodes
+    if (NW <= 1) return 3u * 64u;  // (64 spare) + Hp + the arc list of walk_nodes
     return 64u * NW * NW + 12u + FCM_WIDE_LEVELS * 8u + 16u + FCM_WIDE_LEVELS + 32u * NW;
 }
 __device__ __forceinline__ Wide wide_carve(u64 *smem, int NW)
@@ -754,7 +755,7 @@ template <int MAXT, int MINW, bool CLIQUE, bool EXACT>
 __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];  // fcm_lds_words(p.maxnw) words
-    u64 *Hs = smem, *Hp = smem + WAVE;  // fast path: raw masks and split graph; the wide path reuses the region
+    u64 *Hp = smem + WAVE;  // fast path: the split graph (and the arc list behind it); the wide path reuses the region
     const int lane = threadIdx.x;
     const u32 chain = blockIdx.x;
     if (chain >= p.nchains) return;
@@ -865,26 +866,25 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         {   // same work as flip_eval, with a stamp between build and count
                             u64 myH = build_local(rrows, stride32, Lv, k + 2, lane);
                             FCM_STAMP_AT(2);                           // flip: build
-                            Hs[lane] = myH;
-                            wave_sync();
-                            const u32 ab = (u32)((Hs[k + 1] >> k) & 1ull), ba = (u32)((Hs[k] >> (k + 1)) & 1ull);
+                            const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
+                            const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);
                             if (ab == ba) res = ab ? 0 : -1;
                             else {
                                 const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;
-                                Cls c = classify(myH, Hs, iv, iu);
+                                Cls c = classify(myH, iv, iu);
                                 Cls c2; c2.P = c.P; c2.S = c.S;
-                                c2.M = Hs[iu] & ballot((myH >> iv) & 1ull) & ~(3ull << k);
+                                c2.M = (ab ? hk : hk1) & ballot((myH >> iv) & 1ull) & ~(3ull << k);
                                 if (!extras_fit(c, k + 2) || !extras_fit(c2, k + 2)) res = FCM_NEEDS_WIDE;
                                 else {
-                                    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
-                                    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta);
+                                    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, stamp_acc, &stamp_t);
+                                    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta, stamp_acc, &stamp_t);
                                     res = ab ? 1 : 2;
                                 }
                             }
                             FCM_STAMP_AT(3);                           // flip: two evaluations
                         }
 #else
-                        res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hs, Hp, lane, tmax, delta);
+                        res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hp, lane, tmax, delta);
 #endif
                     }
                     if (res == FCM_NEEDS_WIDE) {
@@ -986,12 +986,12 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         bool okd = true;
                         if (!go_wide) {
                             // (1) remove delme: subtract simplices through it
-                            const int r1 = del_eval<MAXT>(rrows, stride32, Lv1, dk, coin, Hs, Hp, lane, tmax, delta);
+                            const int r1 = del_eval<MAXT>(rrows, stride32, Lv1, dk, coin, Hp, lane, tmax, delta);
                             go_wide = r1 == FCM_NEEDS_WIDE;
                             okd = r1 != 0;
                             if (!go_wide) {
                                 // (2) add eb->ea on the graph without delme: add simplices through it
-                                const int r2 = add_eval_built<MAXT>(myH2, Lv2, rk, rfwd, dfrom, dto, Hs, Hp, lane, tmax, delta);
+                                const int r2 = add_eval_built<MAXT>(myH2, Lv2, rk, rfwd, dfrom, dto, Hp, lane, tmax, delta);
                                 go_wide = r2 == FCM_NEEDS_WIDE;
                             }
                         }

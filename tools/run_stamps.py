@@ -10,7 +10,13 @@ from flag_complex_mcmc_amd import _ffi
 n, chains, props = 1000, int(os.environ.get("FCM_STAMP_CHAINS", "4096")), 512
 CLIQUE = len(sys.argv) > 1 and sys.argv[1] == "clique"   # clique moves only: slots 1..5 then mean the clique phases
 e = fcm.graphs.random_with_p(n, 0.10, 0)
-if CLIQUE:
+FLIPS = len(sys.argv) > 1 and sys.argv[1] == "flips"    # flips only: slots 3..5 then split the evaluation
+if FLIPS:
+    g = fcm.Graph.from_edges(n, e)
+    fc = g.flagser_count(0)
+    b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.01), 0)
+    s = fcm.MCMCSampler(g, b, n_chains=chains, seed=0, move_weights=[1.0, 0.0, 0.0, 0.0])
+elif CLIQUE:
     props = 64
     g = fcm.Graph.from_edges(n, e)
     fc = g.flagser_count(0)
@@ -24,6 +30,9 @@ _ffi.check(_ffi.lib().fcm_sampler_debug_stamps(s._h, out.ctypes.data_as(_ffi.u64
 tot = out.sum(axis=0).astype(float)
 names = ["decode/other", "flip: list round trip", "flip: build", "flip: 2 evaluations", "dmove: lists + candidate build",
          "dmove: build + 2 evaluations", "reduce + bounds + commit", "batch draw"]
+if FLIPS:
+    names = ["decode/other", "flip: list round trip", "flip: build", "eval: classes, seating, split rows (+ tail of slot 5)",
+             "eval: arc scan + scatter", "eval: arcs and deeper levels", "reduce + bounds + commit", "batch draw"]
 if CLIQUE:
     names = ["decode/other", "clique: pick, d, permutations", "clique: OLD gather, NEW, pair list", "clique: pair ids + table entries",
              "clique: per pair list + build", "clique: per pair evaluations + stores", "reduce + bounds + slots/revert", "batch draw"]
