@@ -114,6 +114,9 @@ typedef int (*fcm_step_launcher)(const FcmStepParams *, void *);
 #define FCM_DECL_STEP(tag) int fcm_launch_step_##tag##_0(const FcmStepParams *, void *); int fcm_launch_step_##tag##_1(const FcmStepParams *, void *);
 extern "C" {
 FCM_DECL_STEP(6) FCM_DECL_STEP(14) FCM_DECL_STEP(x2) FCM_DECL_STEP(x3) FCM_DECL_STEP(x4) FCM_DECL_STEP(x5) FCM_DECL_STEP(x6)
+int fcm_launch_step_p2_0(const FcmStepParams *, void *); int fcm_launch_step_p3_0(const FcmStepParams *, void *);
+int fcm_launch_step_p4_0(const FcmStepParams *, void *); int fcm_launch_step_p5_0(const FcmStepParams *, void *);
+int fcm_launch_step_p6_0(const FcmStepParams *, void *);
 }
 
 // tmax = tracked depth (count entries - 2); clique: kernel variant with the clique moves
@@ -124,6 +127,11 @@ extern "C" int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, voi
         {fcm_launch_step_x4_0, fcm_launch_step_x4_1}, {fcm_launch_step_x5_0, fcm_launch_step_x5_1},
         {fcm_launch_step_x6_0, fcm_launch_step_x6_1}};
     const int c = clique ? 1 : 0;
+    if (clique == 2 && tmax >= 2 && tmax <= 6) {   // producer/consumer pair of waves per chain (simple moves)
+        static const fcm_step_launcher pc[5] = {fcm_launch_step_p2_0, fcm_launch_step_p3_0, fcm_launch_step_p4_0,
+                                                fcm_launch_step_p5_0, fcm_launch_step_p6_0};
+        return pc[tmax - 2](p, stream);
+    }
     if (tmax >= 2 && tmax <= 6) return exact[tmax - 2][c](p, stream);
     if (tmax <= 6) return c ? fcm_launch_step_6_1(p, stream) : fcm_launch_step_6_0(p, stream);
     return c ? fcm_launch_step_14_1(p, stream) : fcm_launch_step_14_0(p, stream);

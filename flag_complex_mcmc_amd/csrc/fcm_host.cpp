@@ -940,7 +940,12 @@ extern "C" int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals)
     while (left > 0) {
         const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
         s->params.nprop = chunk;
-        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? 1 : 0, s->stream);
+        // Simple moves on graphs of at most 1024 vertices (rows of one cache line) run as a
+        // producer/consumer pair of waves per chain (fcm_step_pc.hpp); FCM_PC=0 selects the
+        // one-wave kernel for them too.
+        static const bool pc_off = getenv("FCM_PC") && atoi(getenv("FCM_PC")) == 0;
+        const bool use_pc = !pc_off && !s->clique_moves && s->params.stride32 == 32u && s->maxt_variant >= 2 && s->maxt_variant <= 6;
+        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? 1 : (use_pc ? 2 : 0), s->stream);
         if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
         left -= chunk;
     }

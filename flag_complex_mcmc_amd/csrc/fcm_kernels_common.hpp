@@ -257,6 +257,105 @@ __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 
     return act ? ((u64)hlo | ((u64)hhi << 32)) : 0ull;   // lanes >= s read dword 0 of every row: discard
 }
 
+// The same with at most 32 rows in flight (16 + 16), for the producer wave of the two-wave kernel,
+// which has 64 VGPRs: local sets of up to 32 vertices cost one round trip, up to 64 two or three.
+template <int N>
+__device__ __forceinline__ void build16_second(const rsrc_t rsrc, u32 voff, u32 bpos, u32 roff, int s, const u32 (&wa)[16],
+                                               u32 &hlo, u32 &hhi)
+{
+    u32 wb[N];
+    build_issue<16, N, true>(rsrc, voff, roff, s, wb);
+    build_consume<0, 16>(wa, bpos, hlo, hhi);
+    build_consume<16, N>(wb, bpos, hlo, hhi);
+}
+template <int I0>
+__device__ __forceinline__ void build16_more(const rsrc_t rsrc, u32 voff, u32 bpos, u32 roff, int s, u32 &hlo, u32 &hhi)
+{
+    if (s <= I0 + 4) build_tail<I0, 4>(rsrc, voff, bpos, roff, s, hlo, hhi);
+    else if (s <= I0 + 8) build_tail<I0, 8>(rsrc, voff, bpos, roff, s, hlo, hhi);
+    else if (s <= I0 + 12) build_tail<I0, 12>(rsrc, voff, bpos, roff, s, hlo, hhi);
+    else build_tail<I0, 16>(rsrc, voff, bpos, roff, s, hlo, hhi);
+}
+__device__ __forceinline__ u64 build_local16(const rsrc_t rsrc, u32 stride32, u32 Lv, int s, int lane)
+{
+    const bool act = lane < s;
+    const u32 voff = act ? (Lv >> 5) * 4u : 0u;
+    const u32 bpos = Lv & 31u;
+    const u32 roff = Lv * (stride32 * 4u);
+    u32 hlo = 0u, hhi = 0u;
+    if (s <= 16) {
+        build16_more<0>(rsrc, voff, bpos, roff, s, hlo, hhi);
+    } else {
+        u32 wa[16];
+        build_issue<0, 16, false>(rsrc, voff, roff, s, wa);
+        if (s <= 20) build16_second<4>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
+        else if (s <= 24) build16_second<8>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
+        else if (s <= 28) build16_second<12>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
+        else {
+            build16_second<16>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
+            __builtin_amdgcn_sched_barrier(0);  // (keeps the next batch's loads from being hoisted above: 64 VGPRs)
+            if (s > 32) {
+                if (s <= 48) build16_more<32>(rsrc, voff, bpos, roff, s, hlo, hhi);
+                else {
+                    build_tail<32, 16>(rsrc, voff, bpos, roff, s, hlo, hhi);
+                    __builtin_amdgcn_sched_barrier(0);
+                    build16_more<48>(rsrc, voff, bpos, roff, s, hlo, hhi);
+                }
+            }
+        }
+    }
+    return act ? ((u64)hlo | ((u64)hhi << 32)) : 0ull;
+}
+
+// n <= 1024: a row is 32 dwords, one cache line.  One load instruction then fetches two WHOLE rows
+// (lane l: dword l & 31 of row L[2q + (l >> 5)], the vertex fetched from lane 2q + (l >> 5) by
+// ds_bpermute), so a local set needs half as many loads and registers in flight as rows; the lane's bit of row i sits in lane (L[j] >> 5) + 32 (i & 1) of
+// that register and comes over with ds_bpermute (the LDS crossbar, no LDS memory).  Used by the
+// producer wave of the two-wave kernel, which has 64 VGPRs.
+template <int G>
+__device__ __forceinline__ void build128_issue(const rsrc_t rsrc, u32 Lv, u32 sel, u32 dw, int s, u32 (&w)[32])
+{
+    if constexpr (G < 8) {
+        if (8 * G < s) {
+#pragma unroll
+            for (int q = 4 * G; q < 4 * G + 4; ++q) {
+                // the vertex whose row this half-wave reads: L[2q] (lanes 0..31), L[2q+1] (lanes 32..63)
+                const u32 v = (u32)__builtin_amdgcn_ds_bpermute((int)(sel + 8u * q), (int)Lv);
+                w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (v << 7) + dw, 0, 0);
+            }
+            build128_issue<G + 1>(rsrc, Lv, sel, dw, s, w);
+        }
+    }
+}
+template <int G>
+__device__ __forceinline__ void build128_consume(const u32 (&w)[32], u32 src, u32 bpos, int s, u32 &hlo, u32 &hhi)
+{
+    if constexpr (G < 8) {
+        if (8 * G < s) {
+#pragma unroll
+            for (int q = 4 * G; q < 4 * G + 4; ++q) {
+                const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute((int)src, (int)w[q]);
+                const u32 x1 = (u32)__builtin_amdgcn_ds_bpermute((int)(src + 128u), (int)w[q]);
+                const u32 b0 = __builtin_amdgcn_ubfe(x0, bpos, 1u), b1 = __builtin_amdgcn_ubfe(x1, bpos, 1u);
+                if constexpr (G < 4) hlo |= (b0 << (2 * q)) | (b1 << (2 * q + 1));
+                else hhi |= (b0 << (2 * q - 32)) | (b1 << (2 * q + 1 - 32));
+            }
+            build128_consume<G + 1>(w, src, bpos, s, hlo, hhi);
+        }
+    }
+}
+__device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, int s, int lane)
+{
+    u32 w[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) w[q] = 0u;
+    build128_issue<0>(rsrc, Lv, lane >= 32 ? 4u : 0u, (u32)(lane & 31) * 4u, s, w);
+    u32 hlo = 0u, hhi = 0u;
+    build128_consume<0>(w, (Lv >> 5) * 4u, Lv & 31u, s, hlo, hhi);
+    const u64 h = (u64)hlo | ((u64)hhi << 32);
+    return lane < s ? (h & (s >= 64 ? ~0ull : ((1ull << s) - 1ull))) : 0ull;  // rows >= s were read in whole groups of 8
+}
+
 // ---------------------------------------------------------------------------
 // Counting the simplices through an edge u->v on the local set.
 //

@@ -4,6 +4,7 @@
 //            clique walk has exactly that many levels and no depth checks (tags x2_0 .. x6_1);
 //   EXACT=0: tmax <= FCM_MAXT at run time (tags 6_0, 14_0, 6_1, 14_1).
 #include "fcm_kernels_common.hpp"
+#include "fcm_step_pc.hpp"
 
 #if !defined(FCM_MAXT) || !defined(FCM_CLIQUE) || !defined(FCM_EXACT) || !defined(FCM_TAG)
 #error "compile with -DFCM_TAG=.. -DFCM_MAXT=.. -DFCM_EXACT=0|1 -DFCM_CLIQUE=0|1"
@@ -19,6 +20,15 @@
 #define FCM_MINW 1
 #endif
 
+#if defined(FCM_PC) && FCM_PC
+// tags p2_0 .. p6_0: the producer/consumer kernel (two waves per chain), simple moves only
+extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
+{
+    const size_t words = fcm_pc_lds_words(p->maxnw);
+    fcm_step_pc_kernel<FCM_MAXT><<<dim3(p->nchains), dim3(2 * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
+    return (int)hipGetLastError();
+}
+#else
 extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
 {
     size_t words = fcm_lds_words(p->maxnw);
@@ -27,3 +37,4 @@ extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *
         <<<dim3(p->nchains), dim3(WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
     return (int)hipGetLastError();
 }
+#endif
