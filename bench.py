@@ -216,7 +216,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic(args.chains, args.proposals),
-                         "algorithmic_bytes_per_launch": abytes, "kernel": "fcm_step_kernel"},
+                         "algorithmic_bytes_per_launch": abytes,
+                         "kernel": "fcm_step_pc_kernel" if s.info.get("two_wave") else "fcm_step_kernel"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.n, edges, (bounds.flag_count_min, bounds.flag_count_max), args.seed)

@@ -909,7 +909,14 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     I.ncounts = nc;
     I.lossless = lossless ? 1 : 0;
     I.n_chains = C;
-    I.reserved = 0;
+    // Simple moves on graphs of at most 1024 vertices (rows of one cache line) run as a
+    // producer/consumer pair of waves per chain (fcm_step_pc.hpp); FCM_PC=0 selects the
+    // one-wave kernel for them too.
+    {
+        const char *pc_env = getenv("FCM_PC");
+        const bool pc_off = pc_env && atoi(pc_env) == 0;
+        I.two_wave = (!pc_off && !s->clique_moves && g->stride32 == 32u && nc - 2 >= 2 && nc - 2 <= 6) ? 1u : 0u;
+    }
 
     guard.s = nullptr;
     *out = s;
@@ -940,12 +947,7 @@ extern "C" int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals)
     while (left > 0) {
         const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
         s->params.nprop = chunk;
-        // Simple moves on graphs of at most 1024 vertices (rows of one cache line) run as a
-        // producer/consumer pair of waves per chain (fcm_step_pc.hpp); FCM_PC=0 selects the
-        // one-wave kernel for them too.
-        static const bool pc_off = getenv("FCM_PC") && atoi(getenv("FCM_PC")) == 0;
-        const bool use_pc = !pc_off && !s->clique_moves && s->params.stride32 == 32u && s->maxt_variant >= 2 && s->maxt_variant <= 6;
-        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? 1 : (use_pc ? 2 : 0), s->stream);
+        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? 1 : (s->info.two_wave ? 2 : 0), s->stream);
         if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
         left -= chunk;
     }

@@ -615,3 +615,55 @@ def test_single_chain_and_odd_launch_sizes(fcm, oracle):
     e = graphs.random_with_p(90, 0.2, seed=12)
     # n_chains = 1; launches of 0, 1, 63, 64, 65, 127 proposals; default mix
     _run_parity(fcm, oracle, 90, e, n_chains=1, steps=[0, 1, 63, 64, 65, 127, 0, 3], seed=21, weights=(0.1, 0.1, 0.6, 0.2), relaxation=0.05)
+
+
+# ---- the two-wave (producer/consumer) kernel: simple moves, n <= 1024 ----------------------------
+def test_two_wave_kernel_is_selected_and_switchable(fcm, monkeypatch):
+    from flag_complex_mcmc_amd import graphs
+    e = graphs.random_with_p(120, 0.1, seed=3)
+    g = fcm.Graph.from_edges(120, e)
+    fc = g.flagser_count()
+    b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.05))
+    assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["two_wave"] == 1
+    assert fcm.MCMCSampler(g, b, n_chains=2, seed=1, move_weights=fcm.MOVE_DISTRIBUTION).info["two_wave"] == 0  # clique moves
+    monkeypatch.setenv("FCM_PC", "0")
+    assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["two_wave"] == 0
+
+
+def test_two_wave_redo_paths_trajectory_parity(fcm, oracle):
+    """Tiny graphs: consecutive proposals hit the same slot of the reciprocal list or the same pair
+    all the time, so the SERIAL -> REDO -> exact-run path of the two-wave kernel is exercised on a
+    good share of the proposals (and the patching of stale masks on most of the others)."""
+    from flag_complex_mcmc_amd import graphs
+    for n, pr, gseed in ((12, 0.3, 5), (20, 0.3, 3), (9, 0.45, 7)):
+        e = graphs.random_with_p(n, pr, seed=gseed)
+        for w in ((0.5, 0.5, 0.0, 0.0), (0.0, 1.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0)):
+            s, tw = _run_parity(fcm, oracle, n, e, n_chains=4, steps=[1, 2, 3, 61, 64, 700], seed=21, weights=w, relaxation=0.3)
+            assert s.info["two_wave"] == 1
+            assert (s.stats()["status"] == 0).all()
+
+
+def test_two_wave_equals_one_wave_at_scale(fcm, monkeypatch):
+    """Config-3 graph (local sets of 65 vertices included: the wide path inside the two-wave kernel):
+    both kernels must leave identical chains."""
+    from flag_complex_mcmc_amd import graphs
+    n = 1000
+    e = graphs.random_with_p(n, 0.10, seed=0)
+    g = fcm.Graph.from_edges(n, e)
+    fc = g.flagser_count()
+    b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.01))
+    s2 = fcm.MCMCSampler(g, b, n_chains=96, seed=3)
+    monkeypatch.setenv("FCM_PC", "0")
+    s1 = fcm.MCMCSampler(g, b, n_chains=96, seed=3)
+    assert s2.info["two_wave"] == 1 and s1.info["two_wave"] == 0
+    for nstep in (1, 63, 1000, 3000):
+        s1.step(nstep)
+        s2.step(nstep)
+        st1, st2 = s1.stats(), s2.stats()
+        for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "status"):
+            assert (st1[k] == st2[k]).all(), (nstep, k)
+        for c in range(96):
+            assert s1.flag_count(c) == s2.flag_count(c), (nstep, c)
+    for c in (0, 17, 95):
+        assert (s1.edges(c) == s2.edges(c)).all()
+        assert (s1.double_slots(c) == s2.double_slots(c)).all()

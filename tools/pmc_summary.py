@@ -25,8 +25,8 @@ cf = counters("calib_FETCH_SIZE", "calib_kernel", "FETCH_SIZE")
 cw = counters("calib_WRITE_SIZE", "calib_kernel", "WRITE_SIZE")
 fetch_corr = calib_read_bytes / (sum(cf) / len(cf) * 1024.0)
 write_bytes_per_store = (sum(cw[3:]) / len(cw[3:]) * 1024.0) / calib_write_stores
-sf = counters("bench_FETCH_SIZE", "fcm_step_kernel", "FETCH_SIZE")
-sw = counters("bench_WRITE_SIZE", "fcm_step_kernel", "WRITE_SIZE")
+sf = counters("bench_FETCH_SIZE", "fcm_step_", "FETCH_SIZE")
+sw = counters("bench_WRITE_SIZE", "fcm_step_", "WRITE_SIZE")
 bench = json.load(open("%s/bench_FETCH_SIZE.json" % d))
 out = {
     "n_chains": bench["config"]["chains_per_gpu"], "proposals": bench["config"]["proposals_per_step"],

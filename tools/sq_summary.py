@@ -13,7 +13,7 @@ for sub in sorted(glob.glob(d + "/set*/")):
     acc = collections.defaultdict(list)
     byid = collections.defaultdict(dict)
     for r in csv.DictReader(open(f[0])):
-        if "fcm_step_kernel" in r["Kernel_Name"]:
+        if "fcm_step_" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         # a launch shows one row per dimension instance; rocprofv3 csv has one row per (dispatch, counter)
