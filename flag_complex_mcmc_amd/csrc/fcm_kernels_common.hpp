@@ -312,46 +312,58 @@ __device__ __forceinline__ u64 build_local16(const rsrc_t rsrc, u32 stride32, u3
 // ds_bpermute), so a local set needs half as many loads and registers in flight as rows; the lane's bit of row i sits in lane (L[j] >> 5) + 32 (i & 1) of
 // that register and comes over with ds_bpermute (the LDS crossbar, no LDS memory).  Used by the
 // producer wave of the two-wave kernel, which has 64 VGPRs.
-template <int G>
-__device__ __forceinline__ void build128_issue(const rsrc_t rsrc, u32 Lv, u32 sel, u32 dw, int s, u32 (&w)[32])
+// groups of four row pairs (eight rows) G0 .. G1-1, registers w[0 ..]: issue ...
+template <int G, int G0, int G1, int NW>
+__device__ __forceinline__ void build128_issue(const rsrc_t rsrc, u32 Lv, u32 sel, u32 dw, int s, u32 (&w)[NW])
 {
-    if constexpr (G < 8) {
+    if constexpr (G < G1) {
         if (8 * G < s) {
 #pragma unroll
             for (int q = 4 * G; q < 4 * G + 4; ++q) {
                 // the vertex whose row this half-wave reads: L[2q] (lanes 0..31), L[2q+1] (lanes 32..63)
                 const u32 v = (u32)__builtin_amdgcn_ds_bpermute((int)(sel + 8u * q), (int)Lv);
-                w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (v << 7) + dw, 0, 0);
+                w[q - 4 * G0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (v << 7) + dw, 0, 0);
             }
-            build128_issue<G + 1>(rsrc, Lv, sel, dw, s, w);
+            build128_issue<G + 1, G0, G1, NW>(rsrc, Lv, sel, dw, s, w);
         }
     }
 }
-template <int G>
-__device__ __forceinline__ void build128_consume(const u32 (&w)[32], u32 src, u32 bpos, int s, u32 &hlo, u32 &hhi)
+// ... and consume
+template <int G, int G0, int G1, int NW>
+__device__ __forceinline__ void build128_consume(const u32 (&w)[NW], u32 src, u32 bpos, int s, u32 &hlo, u32 &hhi)
 {
-    if constexpr (G < 8) {
+    if constexpr (G < G1) {
         if (8 * G < s) {
 #pragma unroll
             for (int q = 4 * G; q < 4 * G + 4; ++q) {
-                const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute((int)src, (int)w[q]);
-                const u32 x1 = (u32)__builtin_amdgcn_ds_bpermute((int)(src + 128u), (int)w[q]);
+                const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute((int)src, (int)w[q - 4 * G0]);
+                const u32 x1 = (u32)__builtin_amdgcn_ds_bpermute((int)(src + 128u), (int)w[q - 4 * G0]);
                 const u32 b0 = __builtin_amdgcn_ubfe(x0, bpos, 1u), b1 = __builtin_amdgcn_ubfe(x1, bpos, 1u);
                 if constexpr (G < 4) hlo |= (b0 << (2 * q)) | (b1 << (2 * q + 1));
                 else hhi |= (b0 << (2 * q - 32)) | (b1 << (2 * q + 1 - 32));
             }
-            build128_consume<G + 1>(w, src, bpos, s, hlo, hhi);
+            build128_consume<G + 1, G0, G1, NW>(w, src, bpos, s, hlo, hhi);
         }
     }
 }
 __device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, int s, int lane)
 {
-    u32 w[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) w[q] = 0u;
-    build128_issue<0>(rsrc, Lv, lane >= 32 ? 4u : 0u, (u32)(lane & 31) * 4u, s, w);
+    const u32 sel = lane >= 32 ? 4u : 0u, dw = (u32)(lane & 31) * 4u, src = (Lv >> 5) * 4u, bpos = Lv & 31u;
     u32 hlo = 0u, hhi = 0u;
-    build128_consume<0>(w, (Lv >> 5) * 4u, Lv & 31u, s, hlo, hhi);
+    {   // rows 0..47: 24 registers in flight, one round trip
+        u32 w[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) w[q] = 0u;
+        build128_issue<0, 0, 6, 24>(rsrc, Lv, sel, dw, s, w);
+        build128_consume<0, 0, 6, 24>(w, src, bpos, s, hlo, hhi);
+    }
+    if (s > 48) {   // rows 48..63 (one pair in twenty on config 3): a second trip, the registers are free again
+        u32 w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = 0u;
+        build128_issue<6, 6, 8, 8>(rsrc, Lv, sel, dw, s, w);
+        build128_consume<6, 6, 8, 8>(w, src, bpos, s, hlo, hhi);
+    }
     const u64 h = (u64)hlo | ((u64)hhi << 32);
     return lane < s ? (h & (s >= 64 ? ~0ull : ((1ull << s) - 1ull))) : 0ull;  // rows >= s were read in whole groups of 8
 }

@@ -620,21 +620,31 @@ def test_single_chain_and_odd_launch_sizes(fcm, oracle):
 # ---- the two-wave (producer/consumer) kernel: simple moves, n <= 1024 ----------------------------
 def test_two_wave_kernel_is_selected_and_switchable(fcm, monkeypatch):
     from flag_complex_mcmc_amd import graphs
-    e = graphs.random_with_p(120, 0.1, seed=3)
-    g = fcm.Graph.from_edges(120, e)
+    e = graphs.random_with_p(500, 0.12, seed=3)         # about 25 common neighbours per pair: worth a barrier per proposal
+    g = fcm.Graph.from_edges(500, e)
     fc = g.flagser_count()
     b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.05))
-    assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["two_wave"] == 1
+    s = fcm.MCMCSampler(g, b, n_chains=2, seed=1)
+    assert s.info["k_mean"] >= 12 and s.info["two_wave"] == 1
     assert fcm.MCMCSampler(g, b, n_chains=2, seed=1, move_weights=fcm.MOVE_DISTRIBUTION).info["two_wave"] == 0  # clique moves
     monkeypatch.setenv("FCM_PC", "0")
     assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["two_wave"] == 0
+    e2 = graphs.random_with_p(120, 0.1, seed=3)         # sparse: the one-wave kernel unless forced
+    g2 = fcm.Graph.from_edges(120, e2)
+    fc2 = g2.flagser_count()
+    b2 = fcm.Bounds.calculate(g2, fc2, fcm.Bounds.target(fc2, 0.05))
+    monkeypatch.delenv("FCM_PC")
+    assert fcm.MCMCSampler(g2, b2, n_chains=2, seed=1).info["two_wave"] == 0
+    monkeypatch.setenv("FCM_PC", "2")
+    assert fcm.MCMCSampler(g2, b2, n_chains=2, seed=1).info["two_wave"] == 1
 
 
-def test_two_wave_redo_paths_trajectory_parity(fcm, oracle):
-    """Tiny graphs: consecutive proposals hit the same slot of the reciprocal list or the same pair
+def test_two_wave_redo_paths_trajectory_parity(fcm, oracle, monkeypatch):
+    """Tiny graphs (two-wave kernel forced): consecutive proposals hit the same slot of the reciprocal list or the same pair
     all the time, so the SERIAL -> REDO -> exact-run path of the two-wave kernel is exercised on a
     good share of the proposals (and the patching of stale masks on most of the others)."""
     from flag_complex_mcmc_amd import graphs
+    monkeypatch.setenv("FCM_PC", "2")
     for n, pr, gseed in ((12, 0.3, 5), (20, 0.3, 3), (9, 0.45, 7)):
         e = graphs.random_with_p(n, pr, seed=gseed)
         for w in ((0.5, 0.5, 0.0, 0.0), (0.0, 1.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0)):
