@@ -255,17 +255,13 @@ __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
     const int maxnw = p.maxnw < 2 ? 2 : p.maxnw;
     u32 pstatus = 0u;
 
-    // batch draw: lane s holds proposal (q & ~63) + s
-    int l_move = 0;
-    u32 l_coin = 0u;
-    u64 l_idx = 0ull;
     // the proposal prepared (or run) last: its pairs, its slot if it is a double move
     u32 pv_pair1 = PC_NONE, pv_big1 = PC_NONE, pv_small1 = PC_NONE, pv_pair2 = PC_NONE, pv_big2 = PC_NONE, pv_small2 = PC_NONE;
     u32 pv_dslot = PC_NONE;
-    // Table of the static data the next 32 proposals will need (in the LDS region of the wide
-    // evaluator, which wipes it: table_dirty): 12 words per proposal -- the pair entry of a flip
-    // or of a double move's first candidate, the entry of the pair its slot names now (a guess,
-    // verified when the proposal is prepared), candidates 0 and 1.
+    // Table of the next 32 proposals (in the LDS region of the wide evaluator, which wipes it:
+    // table_dirty), 16 words each: the draw (move, coin word, index), the pair entry of a flip or of
+    // a double move's first candidate, the entry of the pair its slot names now (a guess, verified
+    // when the proposal is prepared), candidates 0 and 1.  Lane j fills entry j: "Philox per lane".
     u32 *T = (u32 *)wsm;
     bool table_dirty = true;
 
@@ -300,86 +296,76 @@ __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
 
         // ---- run proposal cq on the exact state (after a REDO; the consumer idles)
         if (do_exact) {
-            // the batch registers may already belong to the batch of cq+1
-            const bool other_batch = cq + 1 < N && ((cq + 1) & 63ull) == 0;
-            for (int pass = 0; pass < (other_batch ? 1 : 0); ++pass) {
-                const u64 t = sampled0 + (cq & ~63ull) + (u64)lane;
+            int x_move;
+            u32 x_coin;
+            u64 x_idx;
+            {   // the draw of proposal cq again (its table entry may be gone)
+                const u64 t = sampled0 + cq;
                 u32 w[4];
                 philox4x32_10((u32)t, (u32)(t >> 32), C.gchain, 0u, C.k0, C.k1, w);
-                l_move = ((u64)w[0] < cum0) ? 0 : (((u64)w[0] < cum1) ? 1 : (((u64)w[0] < cum2) ? 2 : 3));
-                l_coin = w[1];
+                x_move = ((u64)w[0] < cum0) ? 0 : (((u64)w[0] < cum1) ? 1 : (((u64)w[0] < cum2) ? 2 : 3));
+                x_coin = w[1] & 1u;
                 const u64 x64 = (u64)w[2] | ((u64)w[3] << 32);
-                l_idx = l_move >= 2 ? x64 : __umul64hi(x64, l_move == 0 ? Mtot : (u64)D);
+                x_idx = x_move >= 2 ? x64 : __umul64hi(x64, x_move == 0 ? Mtot : (u64)D);
             }
-            const int sx = (int)(cq & 63ull);
             u32 *hdr = slotHdr(cq);
 #ifdef PC_NO_EXACT   // timing experiments only: a REDO becomes an empty proposal
             if (lane < PH_WORDS) hdr[lane] = lane == PH_KIND ? PC_KIND_DELTA : (lane >= PH_PAIR1 && lane <= PH_PAIR2 ? PC_NONE : 0u);
-            (void)sx;
 #else
-            pstatus |= pc_run_exact(C, wsm, maxnw, tmax, slotH1(cq), hdr, (int)rdlane((u32)l_move, sx), rdlane(l_coin, sx) & 1u,
-                                    rdlane64(l_idx, sx), sampled0 + cq, lane);
+            pstatus |= pc_run_exact(C, wsm, maxnw, tmax, slotH1(cq), hdr, x_move, x_coin, x_idx, sampled0 + cq, lane);
 #endif
             table_dirty = true;   // the wide evaluator's LDS region holds the table
             const u32 hv = lane < PH_WORDS ? hdr[lane] : 0u;
             pv_pair1 = rdlane(hv, PH_PAIR1); pv_big1 = rdlane(hv, PH_BIG1); pv_small1 = rdlane(hv, PH_SMALL1);
             pv_pair2 = rdlane(hv, PH_PAIR2); pv_big2 = rdlane(hv, PH_BIG2); pv_small2 = rdlane(hv, PH_SMALL2);
             pv_dslot = rdlane(hv, PH_D_DSLOT);
-            // (a batch of cq+1 drawn before is drawn again by the preparation below: sidx == 0)
         }
 
         // ---- prepare proposal q (ahead of time) into its slot
         if (do_prep) {
-            const int sidx = (int)(q & 63ull);
-            if (sidx == 0 || (st == S_AFTER && ((cq + 1) & 63ull) == 0)) {
-                const u64 t = sampled0 + (q & ~63ull) + (u64)lane;
-                u32 w[4];
-                philox4x32_10((u32)t, (u32)(t >> 32), C.gchain, 0u, C.k0, C.k1, w);
-                l_move = ((u64)w[0] < cum0) ? 0 : (((u64)w[0] < cum1) ? 1 : (((u64)w[0] < cum2) ? 2 : 3));
-                l_coin = w[1];
-                const u64 x64 = (u64)w[2] | ((u64)w[3] << 32);
-                l_idx = l_move >= 2 ? x64 : __umul64hi(x64, l_move == 0 ? Mtot : (u64)D);
-            }
             if ((q & 31ull) == 0 || table_dirty) {
                 const u64 qbase = q & ~31ull;
                 const int j = lane & 31;
-                const int src = (int)(qbase & 63ull) + j;
-                const int mv = __shfl(l_move, src, WAVE);
-                const u64 ix = (u64)(u32)__shfl((int)(u32)l_idx, src, WAVE) | ((u64)(u32)__shfl((int)(u32)(l_idx >> 32), src, WAVE) << 32);
+                const u64 tj = sampled0 + qbase + (u64)j;
+                u32 w[4];
+                philox4x32_10((u32)tj, (u32)(tj >> 32), C.gchain, 0u, C.k0, C.k1, w);
+                const int mv = ((u64)w[0] < cum0) ? 0 : (((u64)w[0] < cum1) ? 1 : (((u64)w[0] < cum2) ? 2 : 3));
+                const u64 x64 = (u64)w[2] | ((u64)w[3] << 32);
+                const u64 ix = mv >= 2 ? x64 : __umul64hi(x64, mv == 0 ? Mtot : (u64)D);
                 FcmEdgeEntry e = {0u, 0u, 0u, 0u}, de = {0u, 0u, 0u, 0u};
                 u32 ed = 0u, c0 = PC_NONE, c1 = PC_NONE;
                 if (mv == 0 && ix < U) e = C.etab[ix];
                 if (mv == 1 && D > 0) {
                     ed = C.dbl[(u32)ix];
                     de = C.etab[ed];
-                    const u64 tt = sampled0 + qbase + (u64)j;
                     u32 v[4];
-                    philox4x32_10((u32)tt, (u32)(tt >> 32), C.gchain, 1u, C.k0, C.k1, v);
+                    philox4x32_10((u32)tj, (u32)(tj >> 32), C.gchain, 1u, C.k0, C.k1, v);
                     const u64 x0 = __umul64hi((u64)v[0] | ((u64)v[1] << 32), Mtot), x1 = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
                     if (x0 < U) { c0 = (u32)x0; e = C.etab[x0]; }
                     if (x1 < U) c1 = (u32)x1;
                 }
                 if (lane < 32) {
-                    u32 *t = T + j * 12;
-                    t[0] = e.big; t[1] = e.small; t[2] = e.nb_off; t[3] = e.k;
-                    t[4] = de.big; t[5] = de.small; t[6] = de.nb_off; t[7] = de.k;
-                    t[8] = ed; t[9] = c0; t[10] = c1;
+                    u32 *t = T + j * 16;
+                    t[0] = (u32)mv; t[1] = w[1]; t[2] = (u32)ix; t[3] = (u32)(ix >> 32);
+                    t[4] = e.big; t[5] = e.small; t[6] = e.nb_off; t[7] = e.k;
+                    t[8] = de.big; t[9] = de.small; t[10] = de.nb_off; t[11] = de.k;
+                    t[12] = ed; t[13] = c0; t[14] = c1;
                 }
                 wave_sync();
                 table_dirty = false;
             }
-            const u32 tv = lane < 12 ? T[(q & 31ull) * 12 + lane] : 0u;   // this proposal's table entry in one read
+            const u32 tv = lane < 16 ? T[(q & 31ull) * 16 + lane] : 0u;   // this proposal's table entry in one read
             u64 *H1 = slotH1(q), *H2 = slotH2(q);
             u32 *hdr = slotHdr(q);
-            const int move = (int)rdlane((u32)l_move, sidx);
-            const u32 coin = rdlane(l_coin, sidx) & 1u;
-            const u64 idx = rdlane64(l_idx, sidx);
+            const int move = (int)rdlane(tv, 0);
+            const u32 coin = rdlane(tv, 1) & 1u;
+            const u64 idx = (u64)rdlane(tv, 2) | ((u64)rdlane(tv, 3) << 32);
             u32 kind = PC_KIND_EMPTY;
             u32 big1 = PC_NONE, small1 = PC_NONE, pair1 = PC_NONE, big2 = PC_NONE, small2 = PC_NONE, pair2 = PC_NONE;
             u32 kk1 = 0u, kk2 = 0u, flags = 0u, dslot = PC_NONE, m11 = 0u, m12 = 0u, m21 = 0u, m22 = 0u, pend = 0u;
             if (move == 0) {
                 if (Mtot > 0 && idx < U) {
-                    const FcmEdgeEntry e = {rdlane(tv, 0), rdlane(tv, 1), rdlane(tv, 2), rdlane(tv, 3)};
+                    const FcmEdgeEntry e = {rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};
                     big1 = e.big; small1 = e.small; pair1 = (u32)idx; kk1 = e.k;
                     if ((int)e.k + 2 <= WAVE) {
                         const u32 Lv = load_list(C.nb, e.nb_off, (int)e.k, e.big, e.small, lane);
@@ -400,11 +386,11 @@ __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
                         kind = PC_KIND_SERIAL;  // the previous double move may rewrite this very slot
                     } else {
                         const u32 ed = C.dbl[dslot];                       // the live entry ...
-                        FcmEdgeEntry de = {rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};  // ... and the table's guess of its pair
-                        const FcmEdgeEntry e0 = {rdlane(tv, 0), rdlane(tv, 1), rdlane(tv, 2), rdlane(tv, 3)};
-                        const PcCand c = pc_find_candidate(C, sampled0 + q, false, pv_pair1, pv_pair2, true, rdlane(tv, 9), rdlane(tv, 10), e0,
+                        FcmEdgeEntry de = {rdlane(tv, 8), rdlane(tv, 9), rdlane(tv, 10), rdlane(tv, 11)};  // ... and the table's guess of its pair
+                        const FcmEdgeEntry e0 = {rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};
+                        const PcCand c = pc_find_candidate(C, sampled0 + q, false, pv_pair1, pv_pair2, true, rdlane(tv, 13), rdlane(tv, 14), e0,
                                                            lane, pstatus);
-                        if (ed != rdlane(tv, 8)) de = C.etab[ed];          // the slot was rewritten since the table was filled
+                        if (ed != rdlane(tv, 12)) de = C.etab[ed];         // the slot was rewritten since the table was filled
                         big1 = de.big; small1 = de.small; pair1 = ed; kk1 = de.k;
                         if (c.serial || (int)de.k + 2 > WAVE) {
                             kind = PC_KIND_SERIAL;
