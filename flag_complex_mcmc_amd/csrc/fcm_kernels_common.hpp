@@ -351,16 +351,12 @@ __device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, in
     const u32 sel = lane >= 32 ? 4u : 0u, dw = (u32)(lane & 31) * 4u, src = (Lv >> 5) * 4u, bpos = Lv & 31u;
     u32 hlo = 0u, hhi = 0u;
     {   // rows 0..47: 24 registers in flight, one round trip
-        u32 w[24];
-#pragma unroll
-        for (int q = 0; q < 24; ++q) w[q] = 0u;
+        u32 w[24];   // (a group of four is consumed under the very condition it is loaded under)
         build128_issue<0, 0, 6, 24>(rsrc, Lv, sel, dw, s, w);
         build128_consume<0, 0, 6, 24>(w, src, bpos, s, hlo, hhi);
     }
     if (s > 48) {   // rows 48..63 (one pair in twenty on config 3): a second trip, the registers are free again
         u32 w[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) w[q] = 0u;
         build128_issue<6, 6, 8, 8>(rsrc, Lv, sel, dw, s, w);
         build128_consume<6, 6, 8, 8>(w, src, bpos, s, hlo, hhi);
     }
