@@ -79,8 +79,9 @@ __device__ __forceinline__ u32 pc_uni(u32 v) { return (u32)__builtin_amdgcn_read
 // where the vertices (big, small) sit in the local list Lv (s entries): ibig | ismall << 8 | 1 << 16, or 0
 __device__ __forceinline__ u32 pc_member(u32 Lv, int s, int lane, u32 big, u32 small)
 {
+    if (big == PC_NONE) return 0u;   // (wave-uniform)
     const u64 mb = ballot(lane < s && Lv == big), ms = ballot(lane < s && Lv == small);
-    if (big == PC_NONE || !mb || !ms) return 0u;
+    if (!mb || !ms) return 0u;
     return (u32)(__ffsll((long long)mb) - 1) | ((u32)(__ffsll((long long)ms) - 1) << 8) | (1u << 16);
 }
 // in-masks: x -> y present <=> bit ix of lane iy.  The pair at (ibig, ismall) now has big->small = bs, small->big = sb.
