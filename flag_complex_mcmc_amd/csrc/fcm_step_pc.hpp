@@ -310,11 +310,7 @@ __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
                 x_idx = x_move >= 2 ? x64 : __umul64hi(x64, x_move == 0 ? Mtot : (u64)D);
             }
             u32 *hdr = slotHdr(cq);
-#ifdef PC_NO_EXACT   // timing experiments only: a REDO becomes an empty proposal
-            if (lane < PH_WORDS) hdr[lane] = lane == PH_KIND ? PC_KIND_DELTA : (lane >= PH_PAIR1 && lane <= PH_PAIR2 ? PC_NONE : 0u);
-#else
             pstatus |= pc_run_exact(C, wsm, maxnw, tmax, slotH1(cq), hdr, x_move, x_coin, x_idx, sampled0 + cq, lane);
-#endif
             table_dirty = true;   // the wide evaluator's LDS region holds the table
             const u32 hv = lane < PH_WORDS ? hdr[lane] : 0u;
             pv_pair1 = rdlane(hv, PH_PAIR1); pv_big1 = rdlane(hv, PH_BIG1); pv_small1 = rdlane(hv, PH_SMALL1);

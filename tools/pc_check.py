@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Driver for the two-wave (producer/consumer) step kernel: parity against the oracle on small
-graphs and timing on config 3, for a given move mix.  FCM_PC=1 selects the two-wave kernel
-(read once per process).  GPU box only.   pc_proto.py parity|bench  w0 w1"""
+graphs (two-wave kernel forced: FCM_PC=2) and timing on config 3 for a given move mix (FCM_PC from
+the environment: 0 = one-wave kernel, unset = the library's choice).  GPU box only.
+pc_check.py parity|bench  w0 w1"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +12,7 @@ from flag_complex_mcmc_amd import graphs
 mode = sys.argv[1]
 w = [float(sys.argv[2]), float(sys.argv[3]), 0.0, 0.0]
 if mode == "parity":
+    os.environ["FCM_PC"] = "2"
     from oracle import oracle_ffi as oracle
     from helpers import setup_pair, compare_chain
     bad = 0

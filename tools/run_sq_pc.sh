@@ -9,7 +9,7 @@ for pc in 0 1; do
   for SET in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
              "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
     i=$((i+1))
-    FCM_PC=$pc timeout -k 10 120 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pc${pc}_set$i -- python3 $ROOT/tools/pc_proto.py bench ${W0:-1} ${W1:-0} > $OUT/pc${pc}_set$i.log 2>&1 || echo "failed pc$pc set $i"
+    FCM_PC=$pc timeout -k 10 120 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pc${pc}_set$i -- python3 $ROOT/tools/pc_check.py bench ${W0:-1} ${W1:-0} > $OUT/pc${pc}_set$i.log 2>&1 || echo "failed pc$pc set $i"
   done
 done
 python3 - <<PY
