@@ -117,6 +117,9 @@ FCM_DECL_STEP(6) FCM_DECL_STEP(14) FCM_DECL_STEP(x2) FCM_DECL_STEP(x3) FCM_DECL_
 int fcm_launch_step_p2_0(const FcmStepParams *, void *); int fcm_launch_step_p3_0(const FcmStepParams *, void *);
 int fcm_launch_step_p4_0(const FcmStepParams *, void *); int fcm_launch_step_p5_0(const FcmStepParams *, void *);
 int fcm_launch_step_p6_0(const FcmStepParams *, void *);
+int fcm_launch_step_q2_0(const FcmStepParams *, void *); int fcm_launch_step_q3_0(const FcmStepParams *, void *);
+int fcm_launch_step_q4_0(const FcmStepParams *, void *); int fcm_launch_step_q5_0(const FcmStepParams *, void *);
+int fcm_launch_step_q6_0(const FcmStepParams *, void *);
 }
 
 // tmax = tracked depth (count entries - 2); clique: kernel variant with the clique moves
@@ -129,8 +132,10 @@ extern "C" int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, voi
     const int c = clique ? 1 : 0;
     if (clique == 2 && tmax >= 2 && tmax <= 6) {   // producer/consumer pair of waves per chain (simple moves)
         static const fcm_step_launcher pc[5] = {fcm_launch_step_p2_0, fcm_launch_step_p3_0, fcm_launch_step_p4_0,
-                                                fcm_launch_step_p5_0, fcm_launch_step_p6_0};
-        return pc[tmax - 2](p, stream);
+                                                fcm_launch_step_p5_0, fcm_launch_step_p6_0};   // rows of one cache line
+        static const fcm_step_launcher qc[5] = {fcm_launch_step_q2_0, fcm_launch_step_q3_0, fcm_launch_step_q4_0,
+                                                fcm_launch_step_q5_0, fcm_launch_step_q6_0};   // longer rows
+        return (p->stride32 == 32u ? pc : qc)[tmax - 2](p, stream);
     }
     if (tmax >= 2 && tmax <= 6) return exact[tmax - 2][c](p, stream);
     if (tmax <= 6) return c ? fcm_launch_step_6_1(p, stream) : fcm_launch_step_6_0(p, stream);

@@ -909,16 +909,16 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     I.ncounts = nc;
     I.lossless = lossless ? 1 : 0;
     I.n_chains = C;
-    // Simple moves on graphs of at most 1024 vertices (rows of one cache line) run as a
-    // producer/consumer pair of waves per chain (fcm_step_pc.hpp); FCM_PC=0 selects the
+    // Simple moves run as a producer/consumer pair of waves per chain (fcm_step_pc.hpp) where that pays; FCM_PC=0 selects the
     // one-wave kernel for them too.
     {
         const char *pc_env = getenv("FCM_PC");
         const bool pc_off = pc_env && atoi(pc_env) == 0;
         // (cheap proposals -- a handful of common neighbours -- do not pay for a barrier each: configs[1] runs 15 % slower that way)
         // ... and local sets beyond 64 vertices take a REDO each: neighbourhoods of about 50 and more stay on the one-wave kernel too
+        // ... and rows longer than a cache line (n > 1024) cost the producer a round trip per 16 rows: configs[3] runs 14 % slower that way
         I.two_wave = (!pc_off && !s->clique_moves && g->stride32 == 32u && nc - 2 >= 2 && nc - 2 <= 6 && I.k_mean >= 12.0 && I.k_mean <= 48.0) ? 1u : 0u;
-        if (pc_env && atoi(pc_env) == 2 && !s->clique_moves && g->stride32 == 32u && nc - 2 >= 2 && nc - 2 <= 6) I.two_wave = 1u;  // FCM_PC=2: whenever possible
+        if (pc_env && atoi(pc_env) == 2 && !s->clique_moves && nc - 2 >= 2 && nc - 2 <= 6) I.two_wave = 1u;  // FCM_PC=2: whenever possible
     }
 
     guard.s = nullptr;

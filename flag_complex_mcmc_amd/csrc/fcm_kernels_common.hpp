@@ -257,52 +257,27 @@ __device__ __forceinline__ u64 build_local(const rsrc_t rsrc, u32 stride32, u32 
     return act ? ((u64)hlo | ((u64)hhi << 32)) : 0ull;   // lanes >= s read dword 0 of every row: discard
 }
 
-// The same with at most 32 rows in flight (16 + 16), for the producer wave of the two-wave kernel,
-// which has 64 VGPRs: local sets of up to 32 vertices cost one round trip, up to 64 two or three.
-template <int N>
-__device__ __forceinline__ void build16_second(const rsrc_t rsrc, u32 voff, u32 bpos, u32 roff, int s, const u32 (&wa)[16],
-                                               u32 &hlo, u32 &hhi)
-{
-    u32 wb[N];
-    build_issue<16, N, true>(rsrc, voff, roff, s, wb);
-    build_consume<0, 16>(wa, bpos, hlo, hhi);
-    build_consume<16, N>(wb, bpos, hlo, hhi);
-}
-template <int I0>
-__device__ __forceinline__ void build16_more(const rsrc_t rsrc, u32 voff, u32 bpos, u32 roff, int s, u32 &hlo, u32 &hhi)
-{
-    if (s <= I0 + 4) build_tail<I0, 4>(rsrc, voff, bpos, roff, s, hlo, hhi);
-    else if (s <= I0 + 8) build_tail<I0, 8>(rsrc, voff, bpos, roff, s, hlo, hhi);
-    else if (s <= I0 + 12) build_tail<I0, 12>(rsrc, voff, bpos, roff, s, hlo, hhi);
-    else build_tail<I0, 16>(rsrc, voff, bpos, roff, s, hlo, hhi);
-}
-__device__ __forceinline__ u64 build_local16(const rsrc_t rsrc, u32 stride32, u32 Lv, int s, int lane)
+// The same as a loop over batches of 16 rows (small code, 16 registers; one round trip per batch): the
+// producer wave of the two-wave kernel on graphs whose rows are longer than a cache line.
+__device__ __forceinline__ u64 build_local_loop16(const rsrc_t rsrc, u32 stride32, u32 Lv, int s, int lane)
 {
     const bool act = lane < s;
     const u32 voff = act ? (Lv >> 5) * 4u : 0u;
     const u32 bpos = Lv & 31u;
     const u32 roff = Lv * (stride32 * 4u);
     u32 hlo = 0u, hhi = 0u;
-    if (s <= 16) {
-        build16_more<0>(rsrc, voff, bpos, roff, s, hlo, hhi);
-    } else {
-        u32 wa[16];
-        build_issue<0, 16, false>(rsrc, voff, roff, s, wa);
-        if (s <= 20) build16_second<4>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
-        else if (s <= 24) build16_second<8>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
-        else if (s <= 28) build16_second<12>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
-        else {
-            build16_second<16>(rsrc, voff, bpos, roff, s, wa, hlo, hhi);
-            __builtin_amdgcn_sched_barrier(0);  // (keeps the next batch's loads from being hoisted above: 64 VGPRs)
-            if (s > 32) {
-                if (s <= 48) build16_more<32>(rsrc, voff, bpos, roff, s, hlo, hhi);
-                else {
-                    build_tail<32, 16>(rsrc, voff, bpos, roff, s, hlo, hhi);
-                    __builtin_amdgcn_sched_barrier(0);
-                    build16_more<48>(rsrc, voff, bpos, roff, s, hlo, hhi);
-                }
-            }
+#pragma nounroll
+    for (int i0 = 0; i0 < s; i0 += 16) {
+        u32 w[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            w[q] = 0u;
+            if (i0 + q < s) w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
         }
+        u32 part = 0u;   // bits i0 .. i0+15 of the mask, at positions 0..15
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part |= __builtin_amdgcn_ubfe(w[q], bpos, 1u) << q;
+        if (i0 < 32) hlo |= part << i0; else hhi |= part << (i0 - 32);
     }
     return act ? ((u64)hlo | ((u64)hhi << 32)) : 0ull;
 }

@@ -107,15 +107,20 @@ struct PcChain {
     u32 U, D, stride32, k0, k1, gchain;
 };
 
-__device__ __forceinline__ u64 pc_build(const u32 *rows, u64 rows_bytes, u32 Lv, int s, int lane)
+// ROWS128: rows of one cache line (n <= 1024) are read whole, two per load; longer rows one dword per
+// lane and row, 16 at a time
+template <bool ROWS128>
+__device__ __forceinline__ u64 pc_build(const u32 *rows, u64 rows_bytes, u32 stride32, u32 Lv, int s, int lane)
 {
-    return build_local_rows128(make_rows_rsrc(rows, rows_bytes), Lv, s, lane);
+    if constexpr (ROWS128) return build_local_rows128(make_rows_rsrc(rows, rows_bytes), Lv, s, lane);
+    else return build_local_loop16(make_rows_rsrc(rows, rows_bytes), stride32, Lv, s, lane);
 }
 
 // Single-edge candidate search of a double move (src/lib.rs:308-313) on the bitmap as it is now.
 // exact == false: a candidate on one of the pairs (pv1, pv2) of the previous proposal, or one that
 // needs the wide path, stops the search (serial).  have01: candidates 0 and 1 (and the entry of 0)
 // come from the producer's table.  The winner's list and masks are returned when its set is narrow.
+template <bool ROWS128>
 __device__ __forceinline__ PcCand pc_find_candidate(const PcChain &C, u64 tt, bool exact, u32 pv1, u32 pv2, bool have01, u32 c0, u32 c1,
                                                     FcmEdgeEntry e0, int lane, u32 &status)
 {
@@ -142,7 +147,7 @@ __device__ __forceinline__ PcCand pc_find_candidate(const PcChain &C, u64 tt, bo
             u32 f, bwd;
             if (ck + 2 <= WAVE) {
                 c.Lv = load_list(C.nb, ce.nb_off, ck, ce.big, ce.small, lane);
-                c.H = pc_build(C.rows, C.rows_bytes, c.Lv, ck + 2, lane);
+                c.H = pc_build<ROWS128>(C.rows, C.rows_bytes, C.stride32, c.Lv, ck + 2, lane);
                 f = (u32)(rdlane64(c.H, ck + 1) >> ck) & 1u;
                 bwd = (u32)(rdlane64(c.H, ck) >> (ck + 1)) & 1u;
             } else {
@@ -166,6 +171,7 @@ __device__ __forceinline__ PcCand pc_find_candidate(const PcChain &C, u64 tt, bo
 // change list and the pairs in the slot (kind DELTA).  A few per ten thousand proposals.  Returns
 // status bits.  (Inlined: as a real call it costs the producer's loop more -- stack traffic at
 // every use of the chain descriptor -- than its registers do.)
+template <bool ROWS128>
 __device__ __forceinline__ u32 pc_run_exact(const PcChain &C, u64 *wsm, int maxnw, int tmax, u64 *H1, u32 *hdr, int move, u32 coin,
                                                       u64 idx, u64 tt, int lane)
 {
@@ -192,7 +198,7 @@ __device__ __forceinline__ u32 pc_run_exact(const PcChain &C, u64 *wsm, int maxn
         dslot = (u32)idx;
         const u32 ed = C.dbl[dslot];
         const FcmEdgeEntry de = C.etab[ed];
-        const PcCand c = pc_find_candidate(C, tt, true, PC_NONE, PC_NONE, false, PC_NONE, PC_NONE, FcmEdgeEntry{0u, 0u, 0u, 0u}, lane, status);
+        const PcCand c = pc_find_candidate<ROWS128>(C, tt, true, PC_NONE, PC_NONE, false, PC_NONE, PC_NONE, FcmEdgeEntry{0u, 0u, 0u, 0u}, lane, status);
         if (c.found) {
             nonempty = 1u; isd = 1u;
             const u32 ea = c.fwd ? c.e.big : c.e.small, eb = c.fwd ? c.e.small : c.e.big;  // ea->eb is the single edge
@@ -227,7 +233,7 @@ __device__ __forceinline__ u32 pc_run_exact(const PcChain &C, u64 *wsm, int maxn
     return status;
 }
 
-template <int MAXT>
+template <int MAXT, bool ROWS128>
 __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
 {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -310,7 +316,7 @@ __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
                 x_idx = x_move >= 2 ? x64 : __umul64hi(x64, x_move == 0 ? Mtot : (u64)D);
             }
             u32 *hdr = slotHdr(cq);
-            pstatus |= pc_run_exact(C, wsm, maxnw, tmax, slotH1(cq), hdr, x_move, x_coin, x_idx, sampled0 + cq, lane);
+            pstatus |= pc_run_exact<ROWS128>(C, wsm, maxnw, tmax, slotH1(cq), hdr, x_move, x_coin, x_idx, sampled0 + cq, lane);
             table_dirty = true;   // the wide evaluator's LDS region holds the table
             const u32 hv = lane < PH_WORDS ? hdr[lane] : 0u;
             pv_pair1 = rdlane(hv, PH_PAIR1); pv_big1 = rdlane(hv, PH_BIG1); pv_small1 = rdlane(hv, PH_SMALL1);
@@ -366,7 +372,7 @@ __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
                     big1 = e.big; small1 = e.small; pair1 = (u32)idx; kk1 = e.k;
                     if ((int)e.k + 2 <= WAVE) {
                         const u32 Lv = load_list(C.nb, e.nb_off, (int)e.k, e.big, e.small, lane);
-                        const u64 myH = pc_build(C.rows, C.rows_bytes, Lv, (int)e.k + 2, lane);
+                        const u64 myH = pc_build<ROWS128>(C.rows, C.rows_bytes, C.stride32, Lv, (int)e.k + 2, lane);
                         m11 = pc_member(Lv, (int)e.k + 2, lane, pv_big1, pv_small1);
                         m12 = pc_member(Lv, (int)e.k + 2, lane, pv_big2, pv_small2);
                         H1[lane] = myH;
@@ -385,7 +391,7 @@ __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
                         const u32 ed = C.dbl[dslot];                       // the live entry ...
                         FcmEdgeEntry de = {rdlane(tv, 8), rdlane(tv, 9), rdlane(tv, 10), rdlane(tv, 11)};  // ... and the table's guess of its pair
                         const FcmEdgeEntry e0 = {rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};
-                        const PcCand c = pc_find_candidate(C, sampled0 + q, false, pv_pair1, pv_pair2, true, rdlane(tv, 13), rdlane(tv, 14), e0,
+                        const PcCand c = pc_find_candidate<ROWS128>(C, sampled0 + q, false, pv_pair1, pv_pair2, true, rdlane(tv, 13), rdlane(tv, 14), e0,
                                                            lane, pstatus);
                         if (ed != rdlane(tv, 12)) de = C.etab[ed];         // the slot was rewritten since the table was filled
                         big1 = de.big; small1 = de.small; pair1 = ed; kk1 = de.k;
@@ -396,7 +402,7 @@ __device__ __forceinline__ void pc_producer(const FcmStepParams &p, u64 *smem)
                             flags |= c.fwd << 1;
                             const int s2 = (int)c.e.k + 2, s1 = (int)de.k + 2;
                             const u32 Lv1 = load_list(C.nb, de.nb_off, (int)de.k, de.big, de.small, lane);
-                            const u64 myH1 = pc_build(C.rows, C.rows_bytes, Lv1, s1, lane);
+                            const u64 myH1 = pc_build<ROWS128>(C.rows, C.rows_bytes, C.stride32, Lv1, s1, lane);
                             m11 = pc_member(Lv1, s1, lane, pv_big1, pv_small1);
                             m12 = pc_member(Lv1, s1, lane, pv_big2, pv_small2);
                             m21 = pc_member(c.Lv, s2, lane, pv_big1, pv_small1);
@@ -666,11 +672,11 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
     }
 }
 
-template <int MAXT>
+template <int MAXT, bool ROWS128>
 __global__ __launch_bounds__(2 * WAVE, 8) void fcm_step_pc_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];
     if (blockIdx.x >= p.nchains) return;
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) pc_producer<MAXT>(p, smem);
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) pc_producer<MAXT, ROWS128>(p, smem);
     else pc_consumer<MAXT>(p, smem);
 }

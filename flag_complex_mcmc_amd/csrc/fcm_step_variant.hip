@@ -21,11 +21,12 @@
 #endif
 
 #if defined(FCM_PC) && FCM_PC
-// tags p2_0 .. p6_0: the producer/consumer kernel (two waves per chain), simple moves only
+// tags p2_0 .. p6_0 (rows of one cache line, FCM_PC=1) and q2_0 .. q6_0 (longer rows, FCM_PC=2): the
+// producer/consumer kernel (two waves per chain), simple moves only
 extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
 {
     const size_t words = fcm_pc_lds_words(p->maxnw);
-    fcm_step_pc_kernel<FCM_MAXT><<<dim3(p->nchains), dim3(2 * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
+    fcm_step_pc_kernel<FCM_MAXT, FCM_PC == 1><<<dim3(p->nchains), dim3(2 * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
     return (int)hipGetLastError();
 }
 #else

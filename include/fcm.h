@@ -233,7 +233,8 @@ typedef struct {
     uint32_t n_chains;
     uint32_t two_wave;         /* 1: steps run in the producer/consumer kernel (two waves per chain), 0: one wave per chain.
                                   The library chooses (simple moves, n <= 1024, mean neighbourhood 12..48, <= 8 count entries);
-                                  environment FCM_PC=0 forces the one-wave kernel, FCM_PC=2 the two-wave one wherever it applies.
+                                  environment FCM_PC=0 forces the one-wave kernel, FCM_PC=2 the two-wave one wherever it can run
+                                  (simple moves, <= 8 count entries; any n).
                                   Trajectories are identical either way. */
 } fcm_sampler_info;
 int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out);
