@@ -8,7 +8,7 @@ import numpy as np
 import flag_complex_mcmc_amd as fcm
 from flag_complex_mcmc_amd import graphs
 bad = 0
-for (n, pr, gseed, chains, launches, props, relax) in [(1000, 0.10, 0, 256, 8, 2048, 0.01), (600, 0.12, 3, 128, 4, 2048, 0.01),
+for (n, pr, gseed, chains, launches, props, relax) in [(1000, 0.10, 0, 4096, 8, 1024, 0.01), (1000, 0.10, 0, 256, 8, 2048, 0.01), (600, 0.12, 3, 128, 4, 2048, 0.01),
                                                          (1000, 0.13, 5, 64, 4, 1024, 0.02), (300, 0.20, 6, 64, 4, 2048, 0.02), (1000, 0.10, 1, 64, 2, 4096, 0.0005),
                                                          (100, 0.25, 9, 64, 4, 4096, 0.05), (4000, 0.05, 0, 64, 2, 2048, 0.01), (2000, 0.06, 2, 64, 2, 2048, 0.01)]:
     e = graphs.random_with_p(n, pr, seed=gseed)
