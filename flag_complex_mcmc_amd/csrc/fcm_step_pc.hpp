@@ -512,6 +512,7 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
             const u32 *hdr = slotHdr(cq);
             u32 *d = decOf(cq);
             const u32 hv = lane < PH_WORDS ? hdr[lane] : 0u;   // the whole header in one LDS read; fields by v_readlane
+            const u64 slot_h1 = H1[lane], slot_h2 = H2[lane];   // (in flight with the header: one LDS round trip, not two)
             const u32 kind = rdlane(hv, PH_KIND);
             bool nonempty = false, is_dmove = false, redo = false;
             u32 clr_from = 0u, clr_to = 0u, set_from = 0u, set_to = 0u, dslot = PC_NONE, dnew = 0u;
@@ -531,7 +532,7 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
             } else if (kind == PC_KIND_FLIP) {
                 const u32 a = rdlane(hv, PH_BIG1), b = rdlane(hv, PH_SMALL1);
                 const int k = (int)rdlane(hv, PH_K1);
-                u64 myH = H1[lane];
+                u64 myH = slot_h1;
                 if (patch) {
                     myH = pc_patch(myH, rdlane(hv, PH_MEM11), lc_bits & 1u, (lc_bits >> 1) & 1u, lane);
                     myH = pc_patch(myH, rdlane(hv, PH_MEM12), (lc_bits >> 2) & 1u, (lc_bits >> 3) & 1u, lane);
@@ -565,7 +566,7 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
                 const int dk = (int)rdlane(hv, PH_K1), rk = (int)rdlane(hv, PH_K2);
                 const u32 flags = rdlane(hv, PH_FLAGS);
                 const u32 coin = flags & 1u, rfwd = (flags >> 1) & 1u;
-                u64 myH1 = H1[lane], myH2 = H2[lane];
+                u64 myH1 = slot_h1, myH2 = slot_h2;
                 if (patch) {
                     const u32 b1 = lc_bits & 1u, s1 = (lc_bits >> 1) & 1u, b2 = (lc_bits >> 2) & 1u, s2 = (lc_bits >> 3) & 1u;
                     myH1 = pc_patch(myH1, rdlane(hv, PH_MEM11), b1, s1, lane);
@@ -607,7 +608,7 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
                 if (rdlane(hv, PH_D_NONEMPTY)) {
                     nonempty = true;
                     is_dmove = rdlane(hv, PH_D_ISDMOVE) != 0u;
-                    if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = (long long)H1[lane];
+                    if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = (long long)slot_h1;
                     clr_from = rdlane(hv, PH_D_CLRF); clr_to = rdlane(hv, PH_D_CLRT);
                     set_from = rdlane(hv, PH_D_SETF); set_to = rdlane(hv, PH_D_SETT);
                     dslot = rdlane(hv, PH_D_DSLOT); dnew = rdlane(hv, PH_D_DNEW);
