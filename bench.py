@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: edge-flip proposals/sec on the BASELINE
-config-3 workload (Erdos-Renyi digraph n=1000, p=0.10, 4096 independent chains
+configs[2] workload (Erdos-Renyi digraph n=1000, p=0.10, 4096 independent chains
 per GPU, `--simple` move mix, target_relaxation 0.01).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W            (any N: launches its own ranks)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 A "step" is one launch of the persistent step kernel: every chain runs
 --proposals iterations of the reference loop src/lib.rs:182-192.  Inputs are
 resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+--config 1..4 selects the other single-GPU shares of BASELINE.json's configs
+(parity-test cases; bench lines for DESIGN.md's table, not the headline).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +26,14 @@ sys.path.insert(0, ROOT)
 
 METRIC = "edge-flip proposals/sec/GPU (n=1k graph); bit-exact simplex counts"  # BASELINE.json
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# BASELINE.json configs[i] -> (description, per-GPU chains, default proposals per chain per step)
+CONFIGS = {
+    1: ("configs[1]: C. elegans stand-in (tests/golden/bug_calc_relax_de.flag, n=279), 1024 chains", 1024, 65536),
+    2: ("configs[2]: Erdos-Renyi digraph n=1000 p=0.10 seed 0, 4096 chains per GPU", 4096, 16384),
+    3: ("configs[3]: Erdos-Renyi digraph n=4000 p=0.05 seed 0, 1024 chains per GPU (8192 over 8)", 1024, 16384),
+    4: ("configs[4]: n=30000, 1M directed edge draws seed 0, 256 chains per GPU (2048 over 8)", 256, 32768),
+}
 
 
 def algorithmic_bytes(d, n):
@@ -31,6 +44,19 @@ def algorithmic_bytes(d, n):
     nchg = int(d.get("n_changes", 0))  # clique moves: every changed directed edge is one (k+2)-row evaluation
     return (int(d["sum_k"]) + 4 * int(d["n_flip"]) + 8 * int(d["n_dmove"]) + 2 * nchg) * W \
         + 64 * int(d["n_flip"]) + 128 * int(d["n_dmove"]) + 64 * nchg + 16 * int(d["n_empty"])
+
+
+def needed_bytes(d, n, mean_k):
+    """Bytes the kernels actually have to move when rows are longer than one 128-B line (n > 1024): a local
+    build reads, of each of its k+2 rows, only the lines that hold the k+2 bit positions it tests.
+    Expected distinct lines per row for k+2 uniform positions among nl lines: nl * (1 - (1 - 1/nl)^(k+2)).
+    Plus the static side: 16 B of table entry and 4k B of vertex list per evaluated edge.  Equals the SURVEY
+    figure (whole rows) up to the static terms once k+2 is several times nl."""
+    nl = max(1, (8 * ((n + 63) // 64) + 127) // 128)
+    s = mean_k + 2.0
+    lines = nl * (1.0 - (1.0 - 1.0 / nl) ** s)
+    evals = int(d["n_flip"]) + 2 * int(d["n_dmove"]) + int(d.get("n_changes", 0))
+    return evals * (s * lines * 128.0 + 16.0 + 4.0 * mean_k + 64.0) + 16.0 * int(d["n_empty"])
 
 
 def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
@@ -58,17 +84,19 @@ def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
             "single_thread_proposals_per_s": 1.0 / per_prop}
 
 
-def load_traffic(n_chains, proposals):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same
-    command (profiles/), or None."""
+def load_traffic(config, n_chains, proposals):
+    """(HBM bytes per launch, source) from the committed rocprofv3 PMC summary of this same command
+    (profiles/pmc_summary.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE
+    passes), or (None, None).  A replay of a profiled run, not a measurement of this one: the source says so."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
-        rec = json.load(open(path))
-        if rec.get("n_chains") == n_chains and rec.get("proposals") == proposals:
-            return rec.get("hbm_bytes_per_launch")
+        recs = json.load(open(path))
+        for rec in (recs if isinstance(recs, list) else [recs]):
+            if rec.get("config", 2) == config and rec.get("n_chains") == n_chains and rec.get("proposals") == proposals:
+                return rec.get("hbm_bytes_per_launch"), "replayed from profiles/pmc_summary.json (%s): rocprofv3 --pmc passes of this command, not this run" % rec.get("tag", "?")
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def log(msg):
@@ -78,13 +106,46 @@ def log(msg):
 T_START = time.perf_counter()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD
+    process -- before this process has made any GPU call, and never an exec -- and leave with its code."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log("no launcher in the environment: starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:8]) + " ..."))
+    return subprocess.call(cmd, env=env)
+
+
+def build_workload(fcm, config, n_arg, p_arg, seed):
+    if config == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import load_flag_fixture
+        n, edges = load_flag_fixture("bug_calc_relax_de.flag")
+    elif config == 2:
+        n = n_arg
+        edges = fcm.graphs.random_with_p(n, p_arg, seed)
+    elif config == 3:
+        n = 4000
+        edges = fcm.graphs.random_with_p(n, 0.05, seed)
+    else:
+        n = 30000
+        edges = fcm.graphs.random_edge_draws(n, 1000000, seed)
+    return n, edges
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
-    ap.add_argument("--proposals", type=int, default=1024, help="proposals per chain per step")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=2, help="BASELINE.json configs[i]; 2 is the headline")
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (0 = the config's stated per-GPU count)")
+    ap.add_argument("--proposals", type=int, default=0, help="proposals per chain per step (0 = the config's default; one launch)")
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--p", type=float, default=0.10)
     ap.add_argument("--seed", type=int, default=0)
@@ -92,6 +153,22 @@ def main():
     ap.add_argument("--moves", choices=["simple", "default"], default="simple",
                     help="simple = [0.5,0.5,0,0] (the headline path); default = the reference's [0.1,0.1,0.6,0.2] with clique moves")
     args = ap.parse_args()
+    if args.chains <= 0:
+        args.chains = CONFIGS[args.config][1]
+    if args.proposals <= 0:
+        args.proposals = CONFIGS[args.config][2] if args.moves == "simple" else 2048
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("FCM_BENCH_LAUNCH_ONLY", "0") == "1":   # launcher test (tests/test_bench_launcher.py): no GPU needed
+        print(json.dumps({"launch_only": True, "rank": rank, "local_rank": local_rank, "world": world}), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -99,12 +176,6 @@ def main():
     import flag_complex_mcmc_amd as fcm
     from flag_complex_mcmc_amd import distributed as fdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available() or fcm.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libfcm has no CPU path")
     # Rehearsal on a 1-GPU box: FCM_BENCH_REHEARSE=1 lets all ranks share GPU 0 and talk over gloo
@@ -116,17 +187,19 @@ def main():
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if rehearse else "nccl"
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
 
-    # ---- workload: synthetic ER digraph, same on every rank ---------------------
-    edges = fcm.graphs.random_with_p(args.n, args.p, args.seed)
-    g = fcm.Graph.from_edges(args.n, edges)
-    log("graph built: %d edges" % len(edges))
+    # ---- workload: synthetic digraph, same on every rank -----------------------
+    n, edges = build_workload(fcm, args.config, args.n, args.p, args.seed)
+    g = fcm.Graph.from_edges(n, edges)
+    log("graph built: n=%d, %d edges" % (n, len(edges)))
     flag_count = g.flagser_count(local_rank)
     log("initial count %s" % flag_count)
     bounds = fcm.Bounds.calculate(g, flag_count, fcm.Bounds.target(flag_count, 0.01), device=local_rank)
@@ -144,9 +217,17 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def gather():
+        """The path's one exchange: every rank's per-chain count vectors and counters to every rank."""
+        st = s.stats()
+        mat = np.stack([st[k] for k in fcm._ffi.STAT_NAMES], axis=1)
+        return st, fdist.gather_counts(s.flag_counts(), mat, device=None if rehearse else dev)
+
     for _ in range(args.warmup):
         s.step(args.proposals, sync=False)
     torch.cuda.synchronize()
+    if world > 1:
+        gather()     # warm the collective too (communicator set-up is not part of a step)
     log("warmup done")
     st0 = s.stats()
 
@@ -159,17 +240,12 @@ def main():
         s.step(args.proposals, sync=False)
     ev1.record()
     torch.cuda.synchronize()
+    st1, (all_counts, all_stats) = gather()   # inside the timed region: the histogram gather is part of the job
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # avg launch duration, HIP events on the launch stream
     log("timed region done: %.3f s, %.2f ms per launch" % (elapsed, kernel_ms))
-
-    # report-time exchange: gather the per-chain count histograms over RCCL
-    st1 = s.stats()
-    counts = s.flag_counts()
-    stat_mat = np.stack([st1[k] for k in fcm._ffi.STAT_NAMES], axis=1)
-    all_counts, all_stats = fdist.gather_counts(counts, stat_mat, device=None if rehearse else dev)
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -177,8 +253,11 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- parity gate on this rank's result (outside the timed region) ----------
-    d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes")}
+    keys = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big")
+    d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in keys}
     assert d["sampled"] == (hi - lo) * args.steps * args.proposals, "proposal count mismatch"
+    assert (st1["status"] == 0).all(), "device-side consistency check failed"
+
     def strip(v):  # flag_count never shrinks in length (src/lib.rs:72-74): ignore trailing zeros
         v = list(v)
         while v and v[-1] == 0:
@@ -188,39 +267,50 @@ def main():
     for c in (0, (hi - lo) // 2, hi - lo - 1):
         assert s.graph(c).flagser_count(local_rank) == strip(s.flag_count(c)), "incremental counts != full recount (chain %d)" % c
         assert bounds.check(s.flag_count(c)), "chain %d left the bounds" % c
+    # the gathered matrix holds every rank's chains, in global chain order
+    assert all_counts.shape[0] == total_chains and (all_stats[:, 0] == all_stats[0, 0]).all()
+    assert (all_counts[lo:hi] == s.flag_counts()).all()
 
     if rank == 0:
         total_prop = total_chains * args.steps * args.proposals
-        abytes = algorithmic_bytes(d, args.n) / args.steps          # per launch, this rank
+        mean_k = float(d["sum_k"]) / max(1.0, float(d["n_flip"] + 2 * d["n_dmove"] + d["n_changes"]))
+        survey_bytes = algorithmic_bytes(d, n) / args.steps             # per launch, this rank
+        long_rows = n > 1024
+        abytes = needed_bytes(d, n, mean_k) / args.steps if long_rows else survey_bytes
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals) if args.moves == "simple" else (None, None)
         out = {
             "metric": METRIC, "value": total_prop / elapsed, "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32/u64 bitset", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: Erdos-Renyi digraph n=%d p=%.2f seed %d, %d chains per GPU, "
-                                   "%d proposals per chain per step, moves %s, target_relaxation 0.01"
-                                   % (args.n, args.p, args.seed, args.chains, args.proposals, list(weights)),
-                       "n": args.n, "p": args.p, "chains_per_gpu": args.chains, "proposals_per_step": args.proposals,
+            "config": {"workload": "BASELINE %s, %d chains per GPU, %d proposals per chain per step, moves %s, target_relaxation 0.01"
+                                   % (CONFIGS[args.config][0], args.chains, args.proposals, list(weights)),
+                       "baseline_config": args.config, "n": n, "chains_per_gpu": args.chains, "proposals_per_step": args.proposals,
                        "edges": int(len(edges)), "initial_flag_count": flag_count, "parallelism": "chains sharded, %d rank(s)" % world},
             "per_gpu_value": total_prop / elapsed / world,
             "kernel_ms_per_launch": kernel_ms,
             "accept_ratio": float(d["accepted"]) / float(d["sampled"]),
             "empty_fraction": float(d["n_empty"]) / float(d["sampled"]),
-            "mean_k": float(d["sum_k"]) / max(1.0, float(d["n_flip"] + 2 * d["n_dmove"] + d["n_changes"])),
+            "mean_k": mean_k,
             "clique_move_fraction": float(d["n_cperm"] + d["n_cswap"]) / float(d["sampled"]),
             "changed_edges_per_clique_move": float(d["n_changes"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"])),
+            "rare_paths_per_1e6": {k: 1e6 * float(d[k]) / float(d["sampled"]) for k in ("n_redo", "n_wide", "n_big")},
             "count_histogram_dim2_distinct": int(len(fdist.count_histogram(all_counts, 2)[0])),
             "parity": "counts == full GPU recount on 3 chains; oracle parity in tests/ -m gpu",
             "gathered_chains": int(all_counts.shape[0]),
+            "collective": {"backend": backend, "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                           "what": "all_gather of per-chain count vectors + counters, inside the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(args.chains, args.proposals),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": abytes,
-                         "kernel": "fcm_step_pc_kernel" if s.info.get("two_wave") else "fcm_step_kernel"},
+                         "algorithmic_model": "lines touched (rows longer than one 128-B line; DESIGN.md 4.3)" if long_rows else "SURVEY.md 8(d): whole rows",
+                         "survey_bytes_per_launch": survey_bytes,
+                         "kernel": s.info.get("kernel_name", "fcm_step_pc_kernel" if s.info.get("two_wave") else "fcm_step_kernel")},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.n, edges, (bounds.flag_count_min, bounds.flag_count_max), args.seed)
+        if world == 1 and not args.no_cpu_baseline and args.config == 2 and args.moves == "simple":
+            out["cpu_baseline"] = cpu_baseline(n, edges, (bounds.flag_count_min, bounds.flag_count_max), args.seed)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

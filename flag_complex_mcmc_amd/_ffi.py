@@ -9,12 +9,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcm.so")
+# FCM_LIB_PATH: a diagnostic build of the same library (tools/run_stamps.sh); never a different implementation
+LIB_PATH = os.environ.get("FCM_LIB_PATH") or os.path.join(_HERE, "libfcm.so")
 
 MAX_COUNTS = 16
-NSTATS = 12
+NSTATS = 16
 STAT_NAMES = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "count_len", "status",
-              "n_cperm", "n_cswap", "n_changes", "reserved")
+              "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big", "reserved14", "reserved15")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_PANIC, ERR_NOMEM, ERR_INTERNAL = range(9)
 

@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 #define FCM_DEV_MAX_COUNTS 16
-#define FCM_DEV_NSTATS 12
+#define FCM_DEV_NSTATS 16
 #define FCM_MAX_SUB 32           // philox blocks (2 candidates each) tried for the single edge of a double-edge move
 #define FCM_LAUNCH_CHUNK (1u << 16)  // proposals per chain per kernel launch
 
@@ -19,7 +19,7 @@ struct FcmEdgeEntry {
 //   rows  [n_chains][n][stride32] u32   out-row bitmaps, one chain after another; row = 128-B multiple
 //   dbl   [n_chains][dbl_stride]  u32   reciprocal-pair slot list (undirected edge ids)
 //   counts[n_chains][16]          u64   flag_count per chain
-//   stats [n_chains][8]           u64   FCM_STAT_* counters
+//   stats [n_chains][16]          u64   FCM_STAT_* counters
 struct FcmStepParams {
     const FcmEdgeEntry *etab;  // [U]
     const uint32_t *nb;        // concatenated neighbour lists

@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -46,18 +48,31 @@ static int fail(int code, const char *fmt, ...)
         if (_e != hipSuccess) return fail(FCM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+// Nothing throws across the C boundary (include/fcm.h): every entry point that can allocate is a
+// function-try-block that ends in one of these.
+static int guard_fail()
+{
+    try { throw; }
+    catch (const std::bad_alloc &) { return fail(FCM_ERR_NOMEM, "out of memory"); }
+    catch (const std::length_error &e) { return fail(FCM_ERR_NOMEM, "allocation size out of range (%s)", e.what()); }
+    catch (const std::exception &e) { return fail(FCM_ERR_INTERNAL, "unexpected exception: %s", e.what()); }
+    catch (...) { return fail(FCM_ERR_INTERNAL, "unexpected exception"); }
+}
+#define FCM_CATCH catch (...) { return guard_fail(); }
+#define FCM_CATCH_PTR catch (...) { (void)guard_fail(); return nullptr; }
+
 extern "C" const char *fcm_last_error(void) { return g_err; }
 extern "C" const char *fcm_version(void) { return "fcm-amd 0.1 (gfx950)"; }
 
 extern "C" int fcm_device_count(int *count)
-{
+try {
     if (!count) return fail(FCM_ERR_INVALID, "count is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) n = 0;
     *count = n;
     return FCM_OK;
-}
+} FCM_CATCH
 
 static int use_device(int device)
 {
@@ -99,7 +114,7 @@ static uint32_t stride_for(uint32_t n)
 }
 
 extern "C" int fcm_graph_new_disconnected(uint32_t nnodes, fcm_graph **out)
-{
+try {
     if (!out) return fail(FCM_ERR_INVALID, "out is NULL");
     // the kernels address one bitmap through a buffer descriptor with 32-bit byte offsets
     if ((uint64_t)nnodes * stride_for(nnodes) * 4ull >= (1ull << 32))
@@ -112,10 +127,10 @@ extern "C" int fcm_graph_new_disconnected(uint32_t nnodes, fcm_graph **out)
     catch (...) { delete g; return fail(FCM_ERR_NOMEM, "out of memory for %u x %u bitmap", nnodes, nnodes); }
     *out = g;
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_graph_from_edges(uint32_t nnodes, uint64_t nedges, const fcm_node *edges, fcm_graph **out)
-{
+try {
     if (nedges && !edges) return fail(FCM_ERR_INVALID, "edges is NULL");
     fcm_graph *g = nullptr;
     int rc = fcm_graph_new_disconnected(nnodes, &g);
@@ -128,35 +143,35 @@ extern "C" int fcm_graph_from_edges(uint32_t nnodes, uint64_t nedges, const fcm_
     }
     *out = g;
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_graph_clone(const fcm_graph *g, fcm_graph **out)
-{
+try {
     if (!g || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     fcm_graph *h = new (std::nothrow) fcm_graph(*g);
     if (!h) return fail(FCM_ERR_NOMEM, "out of memory");
     *out = h;
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" void fcm_graph_destroy(fcm_graph *g) { delete g; }
 extern "C" uint32_t fcm_graph_nnodes(const fcm_graph *g) { return g ? g->n : 0; }
 extern "C" uint64_t fcm_graph_nedges(const fcm_graph *g) { return g ? g->m : 0; }
 
 extern "C" int fcm_graph_has_edge(const fcm_graph *g, fcm_node a, fcm_node b)
-{
+try {
     if (!g || a >= g->n || b >= g->n) return 0;
     return g->has(a, b) ? 1 : 0;
-}
+} FCM_CATCH
 
 extern "C" int fcm_graph_set_edge(fcm_graph *g, fcm_node a, fcm_node b, int present)
-{
+try {
     if (!g) return fail(FCM_ERR_INVALID, "graph is NULL");
     if (a >= g->n || b >= g->n) return fail(FCM_ERR_INVALID, "edge (%u,%u) out of range", a, b);
     if (a == b) return fail(FCM_ERR_INVALID, "self-loop (%u,%u)", a, b);
     g->set(a, b, present != 0);
     return FCM_OK;
-}
+} FCM_CATCH
 extern "C" int fcm_graph_add_edge(fcm_graph *g, fcm_node a, fcm_node b) { return fcm_graph_set_edge(g, a, b, 1); }
 extern "C" int fcm_graph_remove_edge(fcm_graph *g, fcm_node a, fcm_node b) { return fcm_graph_set_edge(g, a, b, 0); }
 
@@ -178,7 +193,7 @@ static void for_each_edge(const fcm_graph &g, F f)
 }
 
 extern "C" int fcm_graph_edges(const fcm_graph *g, fcm_node *out, uint64_t cap, uint64_t *m)
-{
+try {
     if (!g) return fail(FCM_ERR_INVALID, "graph is NULL");
     uint64_t i = 0;
     for_each_edge(*g, [&](uint32_t a, uint32_t b) {
@@ -187,7 +202,7 @@ extern "C" int fcm_graph_edges(const fcm_graph *g, fcm_node *out, uint64_t cap, 
     });
     if (m) *m = i;
     return FCM_OK;
-}
+} FCM_CATCH
 
 // undirected adjacency bitmap: und[a] = out[a] | in[a]
 static std::vector<uint32_t> undirected_bitmap(const fcm_graph &g)
@@ -216,7 +231,7 @@ static void undirected_edge_list(const fcm_graph &g, const std::vector<uint32_t>
 }
 
 extern "C" int fcm_graph_undirected_edges(const fcm_graph *g, fcm_node *out, uint64_t cap, uint64_t *m)
-{
+try {
     if (!g) return fail(FCM_ERR_INVALID, "graph is NULL");
     std::vector<uint32_t> und = undirected_bitmap(*g), ue;
     undirected_edge_list(*g, und, ue);
@@ -224,7 +239,7 @@ extern "C" int fcm_graph_undirected_edges(const fcm_graph *g, fcm_node *out, uin
     if (out) memcpy(out, ue.data(), sizeof(uint32_t) * 2 * (size_t)std::min<uint64_t>(u, cap));
     if (m) *m = u;
     return FCM_OK;
-}
+} FCM_CATCH
 
 // ---------------------------------------------------------------------------
 // device counting (flagser_count)
@@ -297,7 +312,7 @@ static void edge_list(const fcm_graph &g, std::vector<uint32_t> &edges)
 }
 
 extern "C" int fcm_graph_flagser_count(const fcm_graph *g, int device, uint64_t *counts, int cap, int *len)
-{
+try {
     if (!g || !counts || !len) return fail(FCM_ERR_INVALID, "NULL argument");
     std::vector<uint32_t> edges;
     edge_list(*g, edges);
@@ -309,7 +324,7 @@ extern "C" int fcm_graph_flagser_count(const fcm_graph *g, int device, uint64_t 
     for (int d = 0; d < l; ++d) counts[d] = c[d];
     *len = l;
     return FCM_OK;
-}
+} FCM_CATCH
 
 static int default_device()
 {
@@ -319,7 +334,7 @@ static int default_device()
 
 // Legacy symbol, src/flagser.rs:7-10.
 extern "C" size_t *flagser_count_unweighted(size_t nvertices, size_t nedges, const fcm_node (*edges)[2], size_t *res_size)
-{
+try {
     if (res_size) *res_size = 0;
     if (!res_size || nvertices > 0xFFFFFFFFull) { fail(FCM_ERR_INVALID, "bad arguments"); return nullptr; }
     fcm_graph *g = nullptr;
@@ -334,7 +349,7 @@ extern "C" size_t *flagser_count_unweighted(size_t nvertices, size_t nedges, con
     for (int d = 0; d < len; ++d) res[d] = (size_t)c[d];
     *res_size = (size_t)len;
     return res;
-}
+} FCM_CATCH_PTR
 
 // ---------------------------------------------------------------------------
 // .flag I/O (src/io.rs:18-48)
@@ -353,7 +368,7 @@ static void split_spaces(const std::string &line, std::vector<std::string> &tok)
 }
 
 extern "C" int fcm_read_flag_file(const char *path, fcm_graph **out)
-{
+try {
     if (!path || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     std::ifstream f(path, std::ios::binary);
     if (!f) return fail(FCM_ERR_IO, "could not find .flag input file %s", path);
@@ -386,10 +401,10 @@ extern "C" int fcm_read_flag_file(const char *path, fcm_graph **out)
     if (!g) return fail(FCM_ERR_IO, "%s: no vertex line", path);
     *out = g;
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_save_flag_file(const char *path, const fcm_graph *g)
-{
+try {
     if (!path || !g) return fail(FCM_ERR_INVALID, "NULL argument");
     std::ofstream f(path, std::ios::binary);
     if (!f) return fail(FCM_ERR_IO, "Unable to write file %s", path);
@@ -399,7 +414,7 @@ extern "C" int fcm_save_flag_file(const char *path, const fcm_graph *g)
     for_each_edge(*g, [&](uint32_t a, uint32_t b) { f << a << ' ' << b << " 1\n"; });  // ascending = sort_unstable (io.rs:42)
     if (!f) return fail(FCM_ERR_IO, "write to %s failed", path);
     return FCM_OK;
-}
+} FCM_CATCH
 
 // ---------------------------------------------------------------------------
 // Bounds (src/lib.rs:113-161; src/util.rs:53-105; src/bin/sample.rs:89-102)
@@ -423,21 +438,24 @@ static uint64_t ref_factorial(uint64_t x)
 }
 
 // OEIS A058298, n!/(n-k), 1 <= k < n, by rows; first 64 terms (util.rs:98-105)
+static std::vector<uint64_t> make_a058298()
+{
+    std::vector<uint64_t> t;
+    uint64_t fact = 1;
+    for (uint64_t n = 2; t.size() < 64; ++n) {
+        fact *= n;
+        for (uint64_t k = 1; k < n && t.size() < 64; ++k) t.push_back(fact / (n - k));
+    }
+    return t;
+}
 static const std::vector<uint64_t> &a058298()
 {
-    static std::vector<uint64_t> t;
-    if (t.empty()) {
-        uint64_t fact = 1;
-        for (uint64_t n = 2; t.size() < 64; ++n) {
-            fact *= n;
-            for (uint64_t k = 1; k < n && t.size() < 64; ++k) t.push_back(fact / (n - k));
-        }
-    }
+    static const std::vector<uint64_t> t = make_a058298();   // thread-safe initialisation (distinct handles, distinct threads)
     return t;
 }
 
 extern "C" int fcm_target_bounds(const uint64_t *flag_count, int len, double r, fcm_bounds *out)
-{
+try {
     if (!flag_count || !out || len < 0 || len > FCM_MAX_COUNTS) return fail(FCM_ERR_INVALID, "bad arguments");
     memset(out, 0, sizeof *out);
     out->min_len = out->max_len = len;
@@ -449,7 +467,7 @@ extern "C" int fcm_target_bounds(const uint64_t *flag_count, int len, double r, 
         }
     }
     return FCM_OK;
-}
+} FCM_CATCH
 
 static int clique_counts(const fcm_graph &g, int device, uint64_t ncl[FCM_MAX_COUNTS], int *ncl_len, uint64_t *n_undirected)
 {
@@ -464,7 +482,7 @@ static int clique_counts(const fcm_graph &g, int device, uint64_t ncl[FCM_MAX_CO
 
 extern "C" int fcm_bounds_calculate(const fcm_graph *g, const uint64_t *flag_count, int len, const fcm_bounds *target,
                                     int device, fcm_bounds *out, uint64_t *ncliques, int *ncliques_len)
-{
+try {
     if (!g || !flag_count || !target || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     if (len > FCM_MAX_COUNTS) return fail(FCM_ERR_INVALID, "len > %d", FCM_MAX_COUNTS);
     uint64_t ncl[FCM_MAX_COUNTS];
@@ -513,18 +531,21 @@ extern "C" int fcm_bounds_calculate(const fcm_graph *g, const uint64_t *flag_cou
     out->flag_count_max[2] = UINT64_MAX;                // :151
     out->flag_count_max[out->max_len++] = 10;           // :152
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_bounds_check(const fcm_bounds *b, const uint64_t *flag_count, int len)
-{
+try {
     if (!b || !flag_count) return 0;
     return all_le(b->flag_count_min, b->min_len, flag_count, len) && all_le(flag_count, len, b->flag_count_max, b->max_len);
-}
+} FCM_CATCH
 
 extern "C" uint64_t fcm_default_sample_distance(uint64_t nedges)
 {
+    // E = 0: 2*0*log2(0) is NaN, and the reference's `NaN as usize` is 0 (src/bin/sample.rs:102); E = 1 gives 0 too
     const double e = (double)nedges;
-    return (uint64_t)std::ceil(2. * e * std::log2(e));
+    const double d = std::ceil(2. * e * std::log2(e));
+    if (!(d > 0.0) || !std::isfinite(d)) return 0;
+    return d >= 18446744073709551615.0 ? UINT64_MAX : (uint64_t)d;
 }
 
 // ---------------------------------------------------------------------------
@@ -678,7 +699,7 @@ static void move_thresholds(const double w[4], uint64_t cum[4])
 }
 
 extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, const fcm_sampler_config *cfg, fcm_sampler **out)
-{
+try {
     if (!g || !bounds || !cfg || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     if (cfg->n_chains == 0) return fail(FCM_ERR_INVALID, "n_chains must be > 0");
     for (int i = 0; i < 4; ++i)
@@ -924,7 +945,7 @@ extern "C" int fcm_sampler_create(const fcm_graph *g, const fcm_bounds *bounds, 
     guard.s = nullptr;
     *out = s;
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" void fcm_sampler_destroy(fcm_sampler *s)
 {
@@ -934,14 +955,14 @@ extern "C" void fcm_sampler_destroy(fcm_sampler *s)
 }
 
 extern "C" int fcm_sampler_set_stream(fcm_sampler *s, void *hip_stream)
-{
+try {
     if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
     s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals)
-{
+try {
     if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
     int rc = use_device(s->device);
     if (rc) return rc;
@@ -957,27 +978,27 @@ extern "C" int fcm_sampler_step(fcm_sampler *s, uint64_t n_proposals)
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->timed = true;
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_sync(fcm_sampler *s)
-{
+try {
     if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
     int rc = use_device(s->device);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_next(fcm_sampler *s)
-{
+try {
     if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
     int rc = fcm_sampler_step(s, s->cfg.sample_distance);
     if (rc) return rc;
     return fcm_sampler_sync(s);
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_last_step_ms(fcm_sampler *s, float *ms)
-{
+try {
     if (!s || !ms) return fail(FCM_ERR_INVALID, "NULL argument");
     if (!s->timed) return fail(FCM_ERR_INVALID, "no step has been launched");
     int rc = use_device(s->device);
@@ -985,7 +1006,7 @@ extern "C" int fcm_sampler_last_step_ms(fcm_sampler *s, float *ms)
     HIP_TRY(hipEventSynchronize(s->ev1));
     HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_ncounts(const fcm_sampler *s) { return s ? s->params.ncounts : 0; }
 extern "C" uint64_t fcm_sampler_sample_distance(const fcm_sampler *s) { return s ? s->cfg.sample_distance : 0; }
@@ -1004,7 +1025,7 @@ static int fetch_stats(fcm_sampler *s, std::vector<uint64_t> &hs)
 }
 
 extern "C" int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len)
-{
+try {
     if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     std::vector<uint64_t> hs;
     int rc = fetch_stats(s, hs);
@@ -1018,17 +1039,17 @@ extern "C" int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *co
         if (count_len) count_len[c] = (int32_t)hs[(size_t)c * FCM_NSTATS + FCM_STAT_COUNT_LEN];
     }
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out)
-{
+try {
     if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     std::vector<uint64_t> hs;
     int rc = fetch_stats(s, hs);
     if (rc) return rc;
     memcpy(out, hs.data(), hs.size() * sizeof(uint64_t));
     return FCM_OK;
-}
+} FCM_CATCH
 
 static int fetch_rows(fcm_sampler *s, uint32_t chain, std::vector<uint32_t> &rows)
 {
@@ -1042,7 +1063,7 @@ static int fetch_rows(fcm_sampler *s, uint32_t chain, std::vector<uint32_t> &row
 }
 
 extern "C" int fcm_sampler_get_edges(fcm_sampler *s, uint32_t chain, fcm_node *out, uint64_t cap, uint64_t *m)
-{
+try {
     if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
     std::vector<uint32_t> rows;
     int rc = fetch_rows(s, chain, rows);
@@ -1061,11 +1082,11 @@ extern "C" int fcm_sampler_get_edges(fcm_sampler *s, uint32_t chain, fcm_node *o
         }
     if (m) *m = i;
     return FCM_OK;
-}
+} FCM_CATCH
 
 // BitOutput::save record, src/io.rs:152-159 (slot order) and :180-194 (packing)
 extern "C" int fcm_sampler_get_edgebits(fcm_sampler *s, uint32_t chain, uint8_t *out, uint64_t cap, uint64_t *nbytes)
-{
+try {
     if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
     const uint64_t U = s->ue.size() / 2;
     const uint64_t need = (2 * U + 7) / 8;
@@ -1083,10 +1104,10 @@ extern "C" int fcm_sampler_get_edgebits(fcm_sampler *s, uint32_t chain, uint8_t 
         if (has(b, a)) out[(2 * e + 1) >> 3] |= (uint8_t)(1u << ((2 * e + 1) & 7));  // slot [small,big]
     }
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_get_double_slots(fcm_sampler *s, uint32_t chain, uint32_t *out, uint64_t cap, uint64_t *n)
-{
+try {
     if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
     if (chain >= s->params.nchains) return fail(FCM_ERR_INVALID, "chain %u out of range", chain);
     int rc = fcm_sampler_sync(s);
@@ -1098,27 +1119,27 @@ extern "C" int fcm_sampler_get_double_slots(fcm_sampler *s, uint32_t chain, uint
         HIP_TRY(hipMemcpy(out, s->d_dbl.as<uint32_t>() + (size_t)chain * s->params.dbl_stride, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out)
-{
+try {
     if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     *out = s->info;
     return FCM_OK;
-}
+} FCM_CATCH
 
 
 extern "C" int fcm_sampler_get_bounds(const fcm_sampler *s, fcm_bounds *out)
-{
+try {
     if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     *out = s->bounds;
     return FCM_OK;
-}
+} FCM_CATCH
 
 // ---------------------------------------------------------------------------
 // Checkpoint / resume (role of src/io.rs:51-62)
 // ---------------------------------------------------------------------------
-static const char FCM_STATE_MAGIC[8] = {'F', 'C', 'M', 'S', 'T', 'A', 'T', '2'};
+static const char FCM_STATE_MAGIC[8] = {'F', 'C', 'M', 'S', 'T', 'A', 'T', '3'};
 
 struct StateHeader {
     char magic[8];
@@ -1134,7 +1155,7 @@ template <class T> static bool wr(FILE *f, const T *p, size_t cnt) { return cnt 
 template <class T> static bool rd(FILE *f, T *p, size_t cnt) { return cnt == 0 || fread(p, sizeof(T), cnt, f) == cnt; }
 
 extern "C" int fcm_sampler_save_state(fcm_sampler *s, const char *path, uint64_t sample_number)
-{
+try {
     if (!s || !path) return fail(FCM_ERR_INVALID, "NULL argument");
     std::vector<uint64_t> hs;
     int rc = fetch_stats(s, hs);   // syncs; refuses to save a chain whose device-side checks failed
@@ -1167,10 +1188,10 @@ extern "C" int fcm_sampler_save_state(fcm_sampler *s, const char *path, uint64_t
     if (!ok) { remove(tmp.c_str()); return fail(FCM_ERR_IO, "write to %s failed", tmp.c_str()); }
     if (rename(tmp.c_str(), path) != 0) return fail(FCM_ERR_IO, "moving temp state file to %s failed", path);
     return FCM_OK;
-}
+} FCM_CATCH
 
 extern "C" int fcm_sampler_load_state(const char *path, int device, fcm_sampler **out, uint64_t *sample_number)
-{
+try {
     if (!path || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(FCM_ERR_IO, "unable to load state %s", path);
@@ -1178,7 +1199,21 @@ extern "C" int fcm_sampler_load_state(const char *path, int device, fcm_sampler 
     StateHeader h;
     if (!rd(f, &h, 1) || memcmp(h.magic, FCM_STATE_MAGIC, 8) != 0) return fail(FCM_ERR_IO, "%s is not a libfcm state file", path);
     if (h.n_chains == 0 || h.ncounts < 2 || h.ncounts > FCM_MAX_COUNTS) return fail(FCM_ERR_IO, "%s: corrupt header", path);
-    const uint64_t U = h.U, D = h.D, rec = (2 * U + 7) / 8;
+    // Every size below comes from the file: hold the header against the graph it claims and against the
+    // file's length before anything is allocated from it.
+    const uint64_t U = h.U, D = h.D;
+    if (U > (uint64_t)h.n * (h.n ? h.n - 1 : 0) / 2 || D > U) return fail(FCM_ERR_IO, "%s: corrupt header (pair counts)", path);
+    const uint64_t rec = (2 * U + 7) / 8;
+    {
+        if (fseek(f, 0, SEEK_END) != 0) return fail(FCM_ERR_IO, "%s: seek failed", path);
+        const long fsz = ftell(f);
+        if (fsz < 0 || fseek(f, (long)sizeof h, SEEK_SET) != 0) return fail(FCM_ERR_IO, "%s: seek failed", path);
+        const unsigned __int128 want = (unsigned __int128)sizeof h + (unsigned __int128)U * 8u
+            + (unsigned __int128)h.n_chains * ((FCM_MAX_COUNTS + FCM_NSTATS) * 8u)
+            + (unsigned __int128)h.n_chains * ((unsigned __int128)rec + (unsigned __int128)D * 4u);
+        if (want != (unsigned __int128)(uint64_t)fsz)
+            return fail(FCM_ERR_IO, "%s: truncated or corrupt (length %ld does not match its header)", path, fsz);
+    }
     std::vector<uint32_t> ue((size_t)U * 2);
     std::vector<uint64_t> hc((size_t)h.n_chains * FCM_MAX_COUNTS), hs((size_t)h.n_chains * FCM_NSTATS);
     if (!rd(f, ue.data(), ue.size()) || !rd(f, hc.data(), hc.size()) || !rd(f, hs.data(), hs.size()))
@@ -1212,6 +1247,7 @@ extern "C" int fcm_sampler_load_state(const char *path, int device, fcm_sampler 
     if (s->params.U != U || s->params.ncounts != h.ncounts || s->params.nchains != h.n_chains)
         return fail(FCM_ERR_IO, "%s: state does not match the tables rebuilt from it", path);
     // per-chain state
+    std::vector<uint8_t> seen((size_t)U);
     if (fseek(f, chain_pos, SEEK_SET) != 0) return fail(FCM_ERR_IO, "%s: seek failed", path);
     for (uint32_t c = 0; c < h.n_chains; ++c) {
         if (!rd(f, bits.data(), bits.size()) || !rd(f, dbl.data(), dbl.size())) return fail(FCM_ERR_IO, "%s: truncated", path);
@@ -1222,13 +1258,18 @@ extern "C" int fcm_sampler_load_state(const char *path, int device, fcm_sampler 
         for (uint64_t e = 0; e < U; ++e) nd += g->has(ue[2 * e], ue[2 * e + 1]) && g->has(ue[2 * e + 1], ue[2 * e]);
         if (nd != D) return fail(FCM_ERR_IO, "%s: chain %u has %llu reciprocal pairs, header says %llu", path, c,
                                  (unsigned long long)nd, (unsigned long long)D);
+        // the slot list must name exactly the chain's reciprocal pairs, each once (the kernels index etab with it)
+        std::fill(seen.begin(), seen.end(), (uint8_t)0);
+        for (uint64_t j = 0; j < D; ++j) {
+            const uint32_t e = dbl[j];
+            if (e >= U || seen[e] || !(g->has(ue[2 * (size_t)e], ue[2 * (size_t)e + 1]) && g->has(ue[2 * (size_t)e + 1], ue[2 * (size_t)e])))
+                return fail(FCM_ERR_IO, "%s: chain %u: corrupt slot list (entry %llu)", path, c, (unsigned long long)j);
+            seen[e] = 1;
+        }
         if (D) HIP_TRY(hipMemcpy(s->d_dbl.as<uint32_t>() + (size_t)c * s->params.dbl_stride, dbl.data(), (size_t)D * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (s->clique_moves && U) {   // inverse of the slot list
             std::vector<uint32_t> so((size_t)U, 0xFFFFFFFFu);
-            for (uint64_t j = 0; j < D; ++j) {
-                if (dbl[j] >= U) return fail(FCM_ERR_IO, "%s: corrupt slot list", path);
-                so[dbl[j]] = (uint32_t)j;
-            }
+            for (uint64_t j = 0; j < D; ++j) so[dbl[j]] = (uint32_t)j;
             HIP_TRY(hipMemcpy(s->d_slot_of.as<uint32_t>() + (size_t)c * U, so.data(), (size_t)U * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }
@@ -1238,15 +1279,15 @@ extern "C" int fcm_sampler_load_state(const char *path, int device, fcm_sampler 
     sg.s = nullptr;
     *out = s;
     return FCM_OK;
-}
+} FCM_CATCH
 
 
 // Diagnostic: the per-chain cycle sums a -DFCM_STAMP build accumulates (zeros in the product build).
 extern "C" int fcm_sampler_debug_stamps(fcm_sampler *s, uint64_t *out /* [n_chains][8] */)
-{
+try {
     if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     int rc = fcm_sampler_sync(s);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, s->d_dbg.p, (size_t)s->params.nchains * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return FCM_OK;
-}
+} FCM_CATCH

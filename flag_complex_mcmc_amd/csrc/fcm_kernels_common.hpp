@@ -859,6 +859,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 
     u64 sampled = st_g[0], accepted = st_g[1], n_empty = st_g[2], n_flip = st_g[3], n_dmove = st_g[4], sum_k = st_g[5];
     u64 n_cperm = st_g[8], n_cswap = st_g[9], n_changes = st_g[10];
+    u64 n_wide = st_g[12], n_big = st_g[13];   // diagnostics: wide evaluations, local sets beyond 48 vertices
     u32 *slot_of = CLIQUE ? p.slot_of + (size_t)chain * p.U : nullptr;
     u32 count_len = (u32)st_g[6];
     u32 status = (u32)st_g[7];
@@ -987,6 +988,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         c_clr_old = res == 1 ? w_ab : w_ba; c_set_old = res == 1 ? w_ba : w_ab;
                         c_have_old = pre;
                         sum_k += (u64)k;
+                        if (k + 2 > 48) n_big += 1;
                     }
                 }
             } else if (move == 1) {
@@ -1096,6 +1098,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         c_set_from = eb; c_set_to = ea;
                         c_slot = slot; c_newdbl = r;
                         sum_k += (u64)de.k + (u64)rk;
+                        if (dk + 2 > 48 || rk + 2 > 48) n_big += 1;
                     }
                 }
             } else {
@@ -1131,6 +1134,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 if (move == 2) n_cperm += 1; else if (move == 3) n_cswap += 1; else if (is_dmove) n_dmove += 1; else n_flip += 1;
                 long long myd = 0;
                 if (used_wide) {
+                    n_wide += 1;
                     const Wide W = wide_carve(smem, maxnw);
                     if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = W.cnt[lane - 1];
                     wave_sync();
@@ -1203,6 +1207,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         st_g[0] = sampled; st_g[1] = accepted; st_g[2] = n_empty; st_g[3] = n_flip;
         st_g[4] = n_dmove; st_g[5] = sum_k; st_g[6] = count_len; st_g[7] = status;
         st_g[8] = n_cperm; st_g[9] = n_cswap; st_g[10] = n_changes;
+        st_g[12] = n_wide; st_g[13] = n_big;
 #ifdef FCM_STAMP
         for (int q = 0; q < 8; ++q) p.dbgbuf[(size_t)chain * 8 + q] += stamp_acc[q];
 #endif

@@ -499,6 +499,7 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
         const u64 bmax = cl ? p.bmax[lane] : ~0ull;
         u64 sampled = st_g[0], accepted = st_g[1], n_empty = st_g[2], n_flip = st_g[3], n_dmove = st_g[4], sum_k = st_g[5];
         u32 count_len = (u32)st_g[6];
+        u64 n_redo = st_g[11], n_wide = st_g[12], n_big = st_g[13];   // diagnostics
         u32 status = 0u;
         bool in_bounds = ballot(cl && (cnt < bmin || cnt > bmax)) == 0ull;
         // the last commit: its pairs and what became of their two directions
@@ -556,6 +557,7 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
                         clr_from = ab ? a : b; clr_to = ab ? b : a;
                         set_from = clr_to; set_to = clr_from;
                         add_k = (u32)k;
+                        if (k + 2 > 48) n_big += 1;
                         my_pair1 = rdlane(hv, PH_PAIR1);
                         my_bits = ab ? 2u : 1u;
                     }
@@ -601,12 +603,14 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
                     set_from = rfwd ? small2 : big2; set_to = rfwd ? big2 : small2;
                     dslot = rdlane(hv, PH_DSLOT); dnew = rdlane(hv, PH_PAIR2);
                     add_k = (u32)(dk + rk);
+                    if (dk + 2 > 48 || rk + 2 > 48) n_big += 1;
                     my_pair1 = rdlane(hv, PH_PAIR1); my_pair2 = dnew;
                     my_bits = (coin ? 2u : 1u) | (3u << 2);
                 }
             } else if (kind == PC_KIND_DELTA) {
                 if (rdlane(hv, PH_D_NONEMPTY)) {
                     nonempty = true;
+                    n_wide += 1;   // the producer's exact runs go through the wide evaluator
                     is_dmove = rdlane(hv, PH_D_ISDMOVE) != 0u;
                     if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = (long long)slot_h1;
                     clr_from = rdlane(hv, PH_D_CLRF); clr_to = rdlane(hv, PH_D_CLRT);
@@ -619,6 +623,7 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
             }
 
             if (__builtin_expect(redo, 0)) {
+                n_redo += 1;
                 if (lane == 0) d[PD_STATUS] = PC_DEC_REDO;
                 pc_barrier();   // end of this phase
                 pc_barrier();   // the producer runs the proposal; next phase the slot is a DELTA
@@ -668,6 +673,7 @@ __device__ __forceinline__ void pc_consumer(const FcmStepParams &p, u64 *smem)
         if (lane == 0) {
             st_g[0] = sampled; st_g[1] = accepted; st_g[2] = n_empty; st_g[3] = n_flip; st_g[4] = n_dmove; st_g[5] = sum_k;
             st_g[6] = count_len;
+            st_g[11] = n_redo; st_g[12] = n_wide; st_g[13] = n_big;
             if (status) atomicOr((unsigned long long *)&st_g[7], (unsigned long long)status);
         }
     }

@@ -15,6 +15,11 @@
  * Threading: handles are not thread-safe; distinct handles may be used from
  * distinct threads (the reference runs independent `State`s on OS threads,
  * src/bin/all_cxs.rs:33-38).
+ *
+ * Side effect on the caller: every entry point that touches the GPU makes its
+ * `device` (the handle's, or the argument) the calling thread's current HIP
+ * device (hipSetDevice) and leaves it so.  A host application that keeps its
+ * own current device (PyTorch, ...) must set it again after calling in.
  */
 #ifndef FCM_H
 #define FCM_H
@@ -178,7 +183,7 @@ uint64_t fcm_sampler_sample_distance(const fcm_sampler *s);
 int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 
 /* Per-chain counters, out[n_chains][FCM_NSTATS]. */
-#define FCM_NSTATS 12
+#define FCM_NSTATS 16
 #define FCM_STAT_SAMPLED 0    /* MCMCSampler::sampled (src/lib.rs:176) */
 #define FCM_STAT_ACCEPTED 1   /* MCMCSampler::accepted (src/lib.rs:177) */
 #define FCM_STAT_EMPTY 2      /* proposals whose transition was empty */
@@ -190,6 +195,9 @@ int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 #define FCM_STAT_CPERM 8      /* non-empty clique_permute proposals */
 #define FCM_STAT_CSWAP 9      /* non-empty clique_swap proposals */
 #define FCM_STAT_CHANGES 10   /* directed edges changed by clique-move proposals */
+#define FCM_STAT_REDO 11      /* two-wave kernel: proposals the consumer handed back (REDO) for an exact run by the producer */
+#define FCM_STAT_WIDE 12      /* proposals evaluated by the wide (multi-word, LDS) evaluator */
+#define FCM_STAT_BIG 13       /* evaluated local sets of more than 48 vertices (second build trip of the two-wave kernel) */
 int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out);
 
 /* Directed edge list of one chain's current graph, ascending (from,to). */

@@ -136,3 +136,62 @@ def test_graph_generators_are_deterministic(fcm):
     assert graphs.clique(3).tolist() == ka["ex03"]["edges"]
     s = graphs.seoify(graphs.clique(4), seed=0)
     assert len(s) == 10
+
+
+# ---- robustness of the boundary: nothing throws, nothing allocates from unchecked sizes -------
+def _state_header(n, n_chains, U, D, ncounts):
+    """The fixed part of a libfcm state file with a valid magic (layout of StateHeader in fcm_host.cpp)."""
+    import ctypes as C
+    from flag_complex_mcmc_amd import _ffi
+
+    class Header(C.Structure):
+        _fields_ = [("magic", C.c_char * 8), ("sample_number", C.c_uint64), ("n", C.c_uint32), ("n_chains", C.c_uint32),
+                    ("U", C.c_uint64), ("D", C.c_uint64), ("ncounts", C.c_int32), ("reserved", C.c_int32),
+                    ("cfg", _ffi.CSamplerConfig), ("bounds", _ffi.CBounds)]
+    h = Header()
+    h.magic = b"FCMSTAT3"
+    h.n, h.n_chains, h.U, h.D, h.ncounts = n, n_chains, U, D, ncounts
+    h.cfg.n_chains = n_chains
+    h.cfg.move_weights[0] = h.cfg.move_weights[1] = 0.5
+    return bytes(h)
+
+
+@pytest.mark.parametrize("U,D,n_chains,tail", [
+    (2 ** 60, 0, 1, 0),          # would be a 2^63-byte vector (std::length_error -> terminate before the fix)
+    (3, 2 ** 40, 1, 64),         # D > U
+    (3, 1, 2 ** 31, 64),         # chain count the file cannot hold
+    (3, 1, 1, 7),                # plausible header, file too short
+])
+def test_load_state_rejects_corrupt_headers_without_allocating(fcm, tmp_path, U, D, n_chains, tail):
+    p = tmp_path / "bad.state"
+    p.write_bytes(_state_header(4, n_chains, U, D, 4) + b"\0" * tail)
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MCMCSampler.load_state(str(p))
+    assert ei.value.code == 5, str(ei.value)
+
+
+def test_load_state_rejects_old_magic_and_short_files(fcm, tmp_path):
+    p = tmp_path / "old.state"
+    p.write_bytes(b"FCMSTAT2" + b"\0" * 600)
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MCMCSampler.load_state(str(p))
+    assert ei.value.code == 5
+    p.write_bytes(b"FCMSTAT3")
+    with pytest.raises(fcm.FcmError):
+        fcm.MCMCSampler.load_state(str(p))
+
+
+def test_default_sample_distance_edge_cases(fcm, oracle):
+    # E = 0: ceil(2*0*log2(0)) is NaN, `NaN as usize` = 0 in the reference (src/bin/sample.rs:102); E = 1: log2(1) = 0
+    assert fcm.default_sample_distance(0) == 0
+    assert fcm.default_sample_distance(1) == 0
+    assert fcm.default_sample_distance(2) == 4
+    for e in (3, 18, 1961, 100151):
+        assert fcm.default_sample_distance(e) == oracle.default_sample_distance(e)
+
+
+def test_graph_allocation_failure_is_an_error_code(fcm):
+    # 200000 vertices: the bitmap would pass 4 GiB of 32-bit offsets -> FCM_ERR_UNSUPPORTED, not an exception
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.Graph.new_disconnected(200000)
+    assert ei.value.code == 4

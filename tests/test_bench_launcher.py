@@ -1,0 +1,32 @@
+"""CPU: `python bench.py --gpus N` starts its own ranks.  With FCM_BENCH_LAUNCH_ONLY=1 every
+rank reports its coordinates and leaves before anything touches a GPU, so this runs without one."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_self_launches_its_ranks():
+    env = dict(os.environ, FCM_BENCH_LAUNCH_ONLY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted((x["rank"], x["world"]) for x in recs) == [(0, 2), (1, 2)], r.stdout
+    assert "starting 2 ranks" in r.stderr
+
+
+def test_bench_under_a_launcher_does_not_relaunch():
+    env = dict(os.environ, FCM_BENCH_LAUNCH_ONLY="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                       timeout=120, env=env, cwd=ROOT)
+    assert r.returncode == 0 and json.loads(r.stdout.strip())["world"] == 1 and "starting" not in r.stderr
+    # a launcher that disagrees with --gpus is an error, not a silent relaunch
+    env["WORLD_SIZE"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0

@@ -677,3 +677,53 @@ def test_two_wave_equals_one_wave_at_scale(fcm, monkeypatch):
     for c in (0, 17, 95):
         assert (s1.edges(c) == s2.edges(c)).all()
         assert (s1.double_slots(c) == s2.double_slots(c)).all()
+
+
+# ---- the kernel bench.py times, in front of the oracle -----------------------
+def _pick_chains(stats, want):
+    """Chain indices whose run hit the rare paths: wide evaluations first, then REDOs, then big local sets."""
+    order = np.lexsort((-stats["n_big"].astype(np.int64), -stats["n_redo"].astype(np.int64), -stats["n_wide"].astype(np.int64)))
+    return [int(c) for c in order[:want]]
+
+
+def test_bench_kernel_config3_oracle_twins(fcm, oracle):
+    """The config-3 graph itself (ER n=1000 p=0.10 seed 0), the kernel variant bench.py times: oracle twins, tolerance 0,
+    on chains chosen so that the rare paths run: local sets beyond 48 vertices (second build trip), beyond 64 (wide
+    evaluator) and proposals that had to be re-run on the exact state (REDO).  The GPU picks the chains (128 chains x 3000
+    proposals, counters n_big / n_wide / n_redo); the oracle then checks those chains edge for edge."""
+    from flag_complex_mcmc_amd import graphs
+    n, nprop = 1000, 3000
+    e = graphs.random_with_p(n, 0.10, 0)
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, b_g, n_chains=128, seed=0)
+    assert s.info["two_wave"] == 1, "the headline workload must run on the multi-wave kernel"
+    s.step(nprop)
+    st = s.stats()
+    assert (st["status"] == 0).all() and (st["sampled"] == nprop).all()
+    assert st["n_big"].sum() > 0 and st["n_wide"].sum() > 0 and st["n_redo"].sum() > 0, \
+        (int(st["n_big"].sum()), int(st["n_wide"].sum()), int(st["n_redo"].sum()))
+    chosen = _pick_chains(st, 4)
+    assert sum(int(st["n_wide"][c]) for c in chosen) > 0 and sum(int(st["n_redo"][c]) for c in chosen) > 0
+    assert sum(int(st["n_big"][c]) for c in chosen) > 0
+    for c in chosen:
+        tw = oracle.Chain(go, b_o, seed=0, chain_id=c)
+        tw.step(nprop)
+        compare_chain(s, c, tw, ctx=("config3", c))
+    # ... and the same chains again in a fresh sampler, launch sizes that are not multiples of anything
+    s2 = fcm.MCMCSampler(gg, b_g, n_chains=2, seed=0, first_chain_id=chosen[0])
+    tw = oracle.Chain(go, b_o, seed=0, chain_id=chosen[0])
+    for nstep in (1, 31, 33, 1000, 1935):
+        s2.step(nstep)
+        tw.step(nstep)
+        compare_chain(s2, 0, tw, ctx=("config3 split", nstep))
+    assert s2.flag_count(0) == s.flag_count(chosen[0])
+
+
+def test_bench_kernel_natural_selection_oracle_twins(fcm, oracle):
+    """A graph on which the library itself selects the multi-wave kernel (n=500 p=0.12: mean neighbourhood about 25)."""
+    from flag_complex_mcmc_amd import graphs
+    n = 500
+    e = graphs.random_with_p(n, 0.12, seed=3)
+    s, tw = _run_parity(fcm, oracle, n, e, n_chains=4, steps=[3000], seed=2, relaxation=0.05, first_chain_id=40)
+    assert s.info["two_wave"] == 1 and 12 <= s.info["k_mean"] <= 48
+    assert (s.stats()["status"] == 0).all()

@@ -1,9 +1,13 @@
 #!/bin/bash
-# Builds the stamped diagnostic library next to the product one and prints phase shares (GPU box).
+# Builds the stamped diagnostic library (-DFCM_STAMP) in a scratch copy of csrc/ and points
+# run_stamps.py at it through FCM_LIB_PATH, so the product libfcm.so and its objects are never
+# touched (GPU box).  Usage: bash tools/run_stamps.sh flips|clique
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-cd $ROOT/flag_complex_mcmc_amd/csrc
-cp ../libfcm.so /tmp/libfcm_product.so
-make -s clean >/dev/null; make -s -j8 EXTRA=-DFCM_STAMP >/dev/null
-cd $ROOT && python tools/run_stamps.py $1
-cp /tmp/libfcm_product.so flag_complex_mcmc_amd/libfcm.so
+WORK=$(mktemp -d /tmp/fcm_stamp.XXXXXX)
+trap 'rm -rf "$WORK"' EXIT
+mkdir -p $WORK/pkg/csrc $WORK/include
+cp -r $ROOT/flag_complex_mcmc_amd/csrc/. $WORK/pkg/csrc/
+cp $ROOT/include/fcm.h $WORK/include/
+( cd $WORK/pkg/csrc && rm -f *.o && make -s -j8 EXTRA=-DFCM_STAMP OUT=$WORK/libfcm_stamp.so $WORK/libfcm_stamp.so >/dev/null )
+cd $ROOT && FCM_LIB_PATH=$WORK/libfcm_stamp.so python tools/run_stamps.py $1
