@@ -307,7 +307,8 @@ def main():
                          "algorithmic_bytes_per_launch": abytes,
                          "algorithmic_model": "lines touched (rows longer than one 128-B line; DESIGN.md 4.3)" if long_rows else "SURVEY.md 8(d): whole rows",
                          "survey_bytes_per_launch": survey_bytes,
-                         "kernel": s.info.get("kernel_name", "fcm_step_pc_kernel" if s.info.get("two_wave") else "fcm_step_kernel")},
+                         "kernel": "fcm_step_mw_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel",
+                         "waves_per_chain": int(s.info["waves_per_chain"])},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 2 and args.moves == "simple":
             out["cpu_baseline"] = cpu_baseline(n, edges, (bounds.flag_count_min, bounds.flag_count_max), args.seed)

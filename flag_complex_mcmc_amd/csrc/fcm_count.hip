@@ -114,12 +114,12 @@ typedef int (*fcm_step_launcher)(const FcmStepParams *, void *);
 #define FCM_DECL_STEP(tag) int fcm_launch_step_##tag##_0(const FcmStepParams *, void *); int fcm_launch_step_##tag##_1(const FcmStepParams *, void *);
 extern "C" {
 FCM_DECL_STEP(6) FCM_DECL_STEP(14) FCM_DECL_STEP(x2) FCM_DECL_STEP(x3) FCM_DECL_STEP(x4) FCM_DECL_STEP(x5) FCM_DECL_STEP(x6)
-int fcm_launch_step_p2_0(const FcmStepParams *, void *); int fcm_launch_step_p3_0(const FcmStepParams *, void *);
-int fcm_launch_step_p4_0(const FcmStepParams *, void *); int fcm_launch_step_p5_0(const FcmStepParams *, void *);
-int fcm_launch_step_p6_0(const FcmStepParams *, void *);
-int fcm_launch_step_q2_0(const FcmStepParams *, void *); int fcm_launch_step_q3_0(const FcmStepParams *, void *);
-int fcm_launch_step_q4_0(const FcmStepParams *, void *); int fcm_launch_step_q5_0(const FcmStepParams *, void *);
-int fcm_launch_step_q6_0(const FcmStepParams *, void *);
+int fcm_launch_step_m2_0(const FcmStepParams *, void *); int fcm_launch_step_m3_0(const FcmStepParams *, void *);
+int fcm_launch_step_m4_0(const FcmStepParams *, void *); int fcm_launch_step_m5_0(const FcmStepParams *, void *);
+int fcm_launch_step_m6_0(const FcmStepParams *, void *);
+int fcm_launch_step_n2_0(const FcmStepParams *, void *); int fcm_launch_step_n3_0(const FcmStepParams *, void *);
+int fcm_launch_step_n4_0(const FcmStepParams *, void *); int fcm_launch_step_n5_0(const FcmStepParams *, void *);
+int fcm_launch_step_n6_0(const FcmStepParams *, void *);
 }
 
 // tmax = tracked depth (count entries - 2); clique: kernel variant with the clique moves
@@ -130,12 +130,12 @@ extern "C" int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, voi
         {fcm_launch_step_x4_0, fcm_launch_step_x4_1}, {fcm_launch_step_x5_0, fcm_launch_step_x5_1},
         {fcm_launch_step_x6_0, fcm_launch_step_x6_1}};
     const int c = clique ? 1 : 0;
-    if (clique == 2 && tmax >= 2 && tmax <= 6) {   // producer/consumer pair of waves per chain (simple moves)
-        static const fcm_step_launcher pc[5] = {fcm_launch_step_p2_0, fcm_launch_step_p3_0, fcm_launch_step_p4_0,
-                                                fcm_launch_step_p5_0, fcm_launch_step_p6_0};   // rows of one cache line
-        static const fcm_step_launcher qc[5] = {fcm_launch_step_q2_0, fcm_launch_step_q3_0, fcm_launch_step_q4_0,
-                                                fcm_launch_step_q5_0, fcm_launch_step_q6_0};   // longer rows
-        return (p->stride32 == 32u ? pc : qc)[tmax - 2](p, stream);
+    if (clique == 2 && tmax >= 2 && tmax <= 6 && p->mw_waves >= 2) {   // several waves per chain, in-order commit (simple moves)
+        static const fcm_step_launcher mc[5] = {fcm_launch_step_m2_0, fcm_launch_step_m3_0, fcm_launch_step_m4_0,
+                                                fcm_launch_step_m5_0, fcm_launch_step_m6_0};   // rows of one cache line
+        static const fcm_step_launcher nc[5] = {fcm_launch_step_n2_0, fcm_launch_step_n3_0, fcm_launch_step_n4_0,
+                                                fcm_launch_step_n5_0, fcm_launch_step_n6_0};   // longer rows
+        return (p->stride32 == 32u ? mc : nc)[tmax - 2](p, stream);
     }
     if (tmax >= 2 && tmax <= 6) return exact[tmax - 2][c](p, stream);
     if (tmax <= 6) return c ? fcm_launch_step_6_1(p, stream) : fcm_launch_step_6_0(p, stream);

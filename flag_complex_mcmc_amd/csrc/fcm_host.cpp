@@ -930,16 +930,18 @@ try {
     I.ncounts = nc;
     I.lossless = lossless ? 1 : 0;
     I.n_chains = C;
-    // Simple moves run as a producer/consumer pair of waves per chain (fcm_step_pc.hpp) where that pays; FCM_PC=0 selects the
-    // one-wave kernel for them too.
+    // Simple moves run with several waves per chain (fcm_step_mw.hpp): W consecutive proposals in flight, decided in order.
+    // W is chosen so that chains x W fills the chip (8192 wave slots): 2 from 4096 chains up, 16 for 512 and fewer.
+    // FCM_MW=<1|2|4|8|16> overrides (1 = the one-wave kernel).
     {
-        const char *pc_env = getenv("FCM_PC");
-        const bool pc_off = pc_env && atoi(pc_env) == 0;
-        // (cheap proposals -- a handful of common neighbours -- do not pay for a barrier each: configs[1] runs 15 % slower that way)
-        // ... and local sets beyond 64 vertices take a REDO each: neighbourhoods of about 50 and more stay on the one-wave kernel too
-        // ... and rows longer than a cache line (n > 1024) cost the producer a round trip per 16 rows: configs[3] runs 14 % slower that way
-        I.two_wave = (!pc_off && !s->clique_moves && g->stride32 == 32u && nc - 2 >= 2 && nc - 2 <= 6 && I.k_mean >= 12.0 && I.k_mean <= 48.0) ? 1u : 0u;
-        if (pc_env && atoi(pc_env) == 2 && !s->clique_moves && nc - 2 >= 2 && nc - 2 <= 6) I.two_wave = 1u;  // FCM_PC=2: whenever possible
+        uint32_t W = C >= 4096 ? 2u : (C >= 2048 ? 4u : (C >= 1024 ? 8u : 16u));
+        if (const char *e = getenv("FCM_MW")) {
+            const int v = atoi(e);
+            W = (v == 2 || v == 4 || v == 8 || v == 16) ? (uint32_t)v : 1u;
+        }
+        if (s->clique_moves || nc - 2 < 2 || nc - 2 > 6) W = 1u;
+        I.waves_per_chain = W;
+        p.mw_waves = W >= 2 ? W : 0u;
     }
 
     guard.s = nullptr;
@@ -971,7 +973,7 @@ try {
     while (left > 0) {
         const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
         s->params.nprop = chunk;
-        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? 1 : (s->info.two_wave ? 2 : 0), s->stream);
+        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? 1 : (s->info.waves_per_chain >= 2 ? 2 : 0), s->stream);
         if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
         left -= chunk;
     }

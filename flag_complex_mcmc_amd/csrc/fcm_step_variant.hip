@@ -4,7 +4,7 @@
 //            clique walk has exactly that many levels and no depth checks (tags x2_0 .. x6_1);
 //   EXACT=0: tmax <= FCM_MAXT at run time (tags 6_0, 14_0, 6_1, 14_1).
 #include "fcm_kernels_common.hpp"
-#include "fcm_step_pc.hpp"
+#include "fcm_step_mw.hpp"
 
 #if !defined(FCM_MAXT) || !defined(FCM_CLIQUE) || !defined(FCM_EXACT) || !defined(FCM_TAG)
 #error "compile with -DFCM_TAG=.. -DFCM_MAXT=.. -DFCM_EXACT=0|1 -DFCM_CLIQUE=0|1"
@@ -21,12 +21,12 @@
 #endif
 
 #if defined(FCM_PC) && FCM_PC
-// tags p2_0 .. p6_0 (rows of one cache line, FCM_PC=1) and q2_0 .. q6_0 (longer rows, FCM_PC=2): the
-// producer/consumer kernel (two waves per chain), simple moves only
+// tags m2_0 .. m6_0 (rows of one cache line, FCM_PC=1) and n2_0 .. n6_0 (longer rows, FCM_PC=2): the
+// multi-wave kernel (p->mw_waves waves per chain, in-order commit), simple moves only
 extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
 {
-    const size_t words = fcm_pc_lds_words(p->maxnw);
-    fcm_step_pc_kernel<FCM_MAXT, FCM_PC == 1><<<dim3(p->nchains), dim3(2 * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
+    const size_t words = fcm_mw_lds_words(p->maxnw, (int)p->mw_waves);
+    fcm_step_mw_kernel<FCM_MAXT, FCM_PC == 1><<<dim3(p->nchains), dim3(p->mw_waves * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
     return (int)hipGetLastError();
 }
 #else

@@ -239,11 +239,10 @@ typedef struct {
     int32_t ncounts;
     int32_t lossless;          /* 1 if every reachable dimension is tracked */
     uint32_t n_chains;
-    uint32_t two_wave;         /* 1: steps run in the producer/consumer kernel (two waves per chain), 0: one wave per chain.
-                                  The library chooses (simple moves, n <= 1024, mean neighbourhood 12..48, <= 8 count entries);
-                                  environment FCM_PC=0 forces the one-wave kernel, FCM_PC=2 the two-wave one wherever it can run
-                                  (simple moves, <= 8 count entries; any n).
-                                  Trajectories are identical either way. */
+    uint32_t waves_per_chain;  /* 1: one wave per chain (fcm_step_kernel); W = 2, 4, 8, 16: the multi-wave kernel (fcm_step_mw_kernel),
+                                  W consecutive proposals of a chain in flight, decided in order.  The library chooses (simple
+                                  moves, <= 8 count entries; W so that chains x W fills the chip); environment FCM_MW=<W> overrides
+                                  (1 = one-wave kernel).  Trajectories are identical whatever W is. */
 } fcm_sampler_info;
 int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out);
 /* The Bounds the sampler checks against (MCMCSampler::bounds, src/lib.rs:170). */
