@@ -167,7 +167,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if os.environ.get("FCM_BENCH_LAUNCH_ONLY", "0") == "1":   # launcher test (tests/test_bench_launcher.py): no GPU needed
-        print(json.dumps({"launch_only": True, "rank": rank, "local_rank": local_rank, "world": world}), flush=True)
+        sys.stdout.write(json.dumps({"launch_only": True, "rank": rank, "local_rank": local_rank, "world": world}) + "\n")
+        sys.stdout.flush()
         return
 
     import numpy as np

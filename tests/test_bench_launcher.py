@@ -15,7 +15,8 @@ def test_bench_self_launches_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
-    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    import re
+    recs = [json.loads(m) for m in re.findall(r"\{[^{}]*\}", r.stdout)]   # (two ranks may share a line of the pipe)
     assert sorted((x["rank"], x["world"]) for x in recs) == [(0, 2), (1, 2)], r.stdout
     assert "starting 2 ranks" in r.stderr
 
