@@ -32,9 +32,12 @@
 // waves each (W = 4, 8, 16), which is what keeps the GPU busy on the per-GPU
 // shares of the 8-GPU configs (1024 and 256 chains).
 //
-// Memory ordering: head is read with acquire and written with release at
-// workgroup scope; all waves of a workgroup run on one CU and share its vector
-// L1, which is what workgroup scope means on gfx950.
+// Memory ordering.  head orders LDS only (log, counts): it is passed on without waiting for the commit's global stores.
+// Visibility of those stores is tracked apart: wave w publishes vis[w] = "every proposal of mine below this index is
+// in memory" at the start of each proposal, after its own earlier stores have completed (s_waitcnt vmcnt(0), long
+// hidden behind the decision's tail).  snap = min over the waves of vis: every proposal below snap is visible to
+// whatever the wave loads from then on; the decisions snap..q-1 -- at most 2W-1 of them, the log keeps 2W -- are held
+// against its reads.  All waves of a workgroup run on one CU and share its vector L1: workgroup scope.
 #pragma once
 
 #define MW_NONE 0xFFFFFFFFu
@@ -43,16 +46,31 @@ enum { ML_FLAGS = 0, ML_BIG1, ML_SMALL1, ML_ID1, ML_BIG2, ML_SMALL2, ML_ID2, ML_
 #define ML_ACCEPTED 1u
 #define ML_DMOVE 2u
 
+// chain context, u32 words in LDS: what the out-of-line parts (table fill, exact run) need, so that the hot loop
+// does not have to keep it in registers
+enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SEED = 10, MC_SAMPLED0 = 12, MC_CUM0 = 14, MC_CUM1 = 16,
+       MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_WORDS = 28 };
+
+// result of an exact run, u32 words in the wave's LDS
+enum { MX_FLAGS = 0, MX_WCLR, MX_WSET, MX_BCLR, MX_BSET, MX_OCLR, MX_OSET, MX_DSLOT, MX_DNEW, MX_ADDK, MX_ID1, MX_BIG1, MX_SMALL1, MX_ID2,
+       MX_BIG2, MX_SMALL2, MX_SUS, MX_WORDS = 32 };   // + myd[16] as u64 behind
+#define MXF_NONEMPTY 1u
+#define MXF_DMOVE 2u
+#define MXF_WIDE 4u
+#define MXF_BIG 8u
+
 // LDS map in u64 words:
-//   shared    cnt[16] | bmin[16] | bmax[16] | ctl[4] | log[W][6]
-//   per wave  Hp[64] | arc list[64] | draw table: 32 entries of 14 u32 [224]
+//   shared    cnt[8] | bmin[8] | bmax[8] | ctl[2] | ctx[14] | vis[8] | log[2W][6]     (<= 8 count entries: tmax <= 6)
+//   per wave  Hp[64] | arc list[64] | draw table: 32 entries of 14 u32 [224]   (the arc list doubles as the exact run's result)
 //   wide evaluator (one: only the token holder runs it)
-#define MW_SHARED_WORDS 52u
+#define MW_SHARED_WORDS 48u
+#define MW_CTX_OFF 26u
+#define MW_VIS_OFF 40u
 #define MW_TBL_WORDS 14u
 #define MW_WAVE_WORDS (128u + 16u * MW_TBL_WORDS)
 __host__ __device__ inline unsigned fcm_mw_lds_words(int NW, int W)
 {
-    return MW_SHARED_WORDS + 6u * W + (unsigned)W * MW_WAVE_WORDS + fcm_lds_words(NW < 2 ? 2 : NW);
+    return MW_SHARED_WORDS + 12u * W + (unsigned)W * MW_WAVE_WORDS + fcm_lds_words(NW < 2 ? 2 : NW);
 }
 
 __device__ __forceinline__ void mw_barrier()   // orders LDS only
@@ -62,6 +80,7 @@ __device__ __forceinline__ void mw_barrier()   // orders LDS only
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 __device__ __forceinline__ u32 mw_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 mw_uni64(u64 v) { return (u64)mw_uni((u32)v) | ((u64)mw_uni((u32)(v >> 32)) << 32); }
 
 template <bool ROWS128>
 __device__ __forceinline__ u64 mw_build(const rsrc_t rr, u32 stride32, u32 Lv, int s, int lane)
@@ -73,6 +92,380 @@ __device__ __forceinline__ u64 mw_build(const rsrc_t rr, u32 stride32, u32 Lv, i
 // both endpoints of the pair (big, small) in the local list Lv?  (lanes beyond the list repeat its last vertex)
 __device__ __forceinline__ bool mw_inside(u32 Lv, u32 big, u32 small) { return ballot(Lv == big) != 0ull && ballot(Lv == small) != 0ull; }
 
+// min over the waves of vis[]: every proposal below it is visible to what this wave loads from now on (acquire)
+__device__ __forceinline__ u32 mw_vis_min(const u32 *vis, u32 W, int lane)
+{
+    u32 v = lane < 16 ? __hip_atomic_load(&vis[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : MW_NONE;   // (entries >= W hold MW_NONE)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)MW_NONE, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)MW_NONE, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)MW_NONE, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)MW_NONE, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    return rdlane(v, 15);
+}
+
+struct MwProp;
+// wave-uniform view of the chain
+struct MwChain {
+    u32 *rows, *dbl;
+    const u32 *nb;
+    const FcmEdgeEntry *etab;
+    u64 rows_bytes;
+    u32 U, D, stride32;
+};
+__device__ __forceinline__ MwChain mw_chain_from_lds(const u32 *ctx, int lane)
+{
+    const u32 cv = lane < MC_WORDS ? ctx[lane] : 0u;
+    MwChain C;
+    C.rows = (u32 *)((u64)rdlane(cv, MC_ROWS) | ((u64)rdlane(cv, MC_ROWS + 1) << 32));
+    C.dbl = (u32 *)((u64)rdlane(cv, MC_DBL) | ((u64)rdlane(cv, MC_DBL + 1) << 32));
+    C.nb = (const u32 *)((u64)rdlane(cv, MC_NB) | ((u64)rdlane(cv, MC_NB + 1) << 32));
+    C.etab = (const FcmEdgeEntry *)((u64)rdlane(cv, MC_ETAB) | ((u64)rdlane(cv, MC_ETAB + 1) << 32));
+    C.rows_bytes = (u64)rdlane(cv, MC_ROWS_BYTES) | ((u64)rdlane(cv, MC_ROWS_BYTES + 1) << 32);
+    C.U = rdlane(cv, MC_U); C.D = rdlane(cv, MC_D); C.stride32 = rdlane(cv, MC_STRIDE32);
+    return C;
+}
+
+// what a run of a proposal leaves behind (wave-uniform unless noted)
+struct MwProp {
+    u32 nonempty, is_dmove, used_wide, big_set, need_exact;   // 0 / 1
+    u32 wid_clr, wid_set, bit_clr, bit_set, w_clr, w_set, dslot, dnew, add_k;
+    u32 id1, big1, small1, id2, big2, small2, cx0, cx1, sus, snap;
+    u32 Lv1, Lv2;       // per lane: the local vertex lists the run read
+    long long myd;      // per lane: lane d holds the change of count[d]
+};
+
+// the log entry of a proposal, all but its ACCEPTED bit, into the wave's staging words (lane 0 writes: scalars)
+__device__ __forceinline__ void mw_stage(u32 *stage, const MwProp &R, int lane)
+{
+    if (lane == 0) {
+        *(uint4 *)(stage + 0) = make_uint4(R.is_dmove << 1, R.big1, R.small1, R.id1);
+        *(uint4 *)(stage + 4) = make_uint4(R.big2, R.small2, R.id2, R.dslot);
+        *(uint2 *)(stage + 8) = make_uint2(R.wid_clr, R.wid_set);
+    }
+    wave_sync();
+}
+
+// One proposal on the bitmap as it is (reference Transition::random_move + State::apply_transition,
+// src/lib.rs:207-212, 292-325, 61-79).  tv = the proposal's draw-table entry (lane i = word i).
+// EXACT = false: the hot path -- two single-edge candidates, local sets of <= 64 vertices whose split graph fits; anything
+// else sets need_exact and is left to the exact run.  EXACT = true: the whole of it (candidate search to the end, wide
+// evaluator), on a state nobody else changes meanwhile.
+template <int MAXT, bool ROWS128, bool EXACT>
+__device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds, int maxnw, u32 tv, u64 tt, u32 gchain, u64 seed, int lane, MwProp &R,
+                                       u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u)
+{
+    const int tmax = MAXT;
+    // The snap point (hot path only): between the static loads of the proposal (table entry, vertex lists) and its first
+    // load of mutable state.  The wave's earlier commit stores have completed by then (s_waitcnt vmcnt(0), which the
+    // vertex list needs anyway): publish that, and note from where on decisions have to be held against this proposal.
+    bool snapped = false;
+    auto snap_point = [&]() {
+        if constexpr (!EXACT) {
+            if (!snapped) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&vis[wv], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                R.snap = mw_vis_min(vis, W, lane);
+                snapped = true;
+            }
+        }
+    };
+    R.nonempty = R.is_dmove = R.used_wide = R.big_set = R.need_exact = 0u;
+    R.wid_clr = R.wid_set = MW_NONE; R.bit_clr = R.bit_set = 0u; R.w_clr = R.w_set = 0u; R.dslot = MW_NONE; R.dnew = 0u; R.add_k = 0u;
+    R.id1 = R.big1 = R.small1 = R.id2 = R.big2 = R.small2 = R.cx0 = R.cx1 = MW_NONE; R.sus = 0u;
+    R.Lv1 = MW_NONE; R.Lv2 = MW_NONE;
+    R.myd = 0; R.snap = 0u;
+    const int move = (int)(rdlane(tv, 0) & 0xFFu);
+    const u32 coin = (rdlane(tv, 0) >> 8) & 1u;
+    const u64 idx = (u64)rdlane(tv, 2) | ((u64)rdlane(tv, 3) << 32);
+    const u32 U = C.U, stride32 = C.stride32;
+    const u64 Mtot = (u64)U + C.D;
+    const rsrc_t rr = make_rows_rsrc(C.rows, C.rows_bytes);
+
+    // what is to be evaluated on the fast path: two (masks, classes, size), signs -1 and +1
+    int nev = 0;
+    u64 HA = 0ull, HB = 0ull;
+    Cls cA = {0ull, 0ull, 0ull}, cB = {0ull, 0ull, 0ull};
+    int kA = 0, kB = 0;
+    bool go_wide = false;
+
+    if (move == 0) {
+        // ---- single_edge_flip (src/lib.rs:292-299)
+        if (Mtot > 0 && idx < U) {
+            const FcmEdgeEntry e1 = {rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};
+            const int k = (int)e1.k;
+            int fres = 0;          // 1 = big->small is flipped, 2 = small->big
+            R.id1 = (u32)idx; R.big1 = e1.big; R.small1 = e1.small;
+            const u32 wid_bs = e1.big * stride32 + (e1.small >> 5), wid_sb = e1.small * stride32 + (e1.big >> 5);   // the words of big->small, small->big
+            if (k + 2 <= WAVE) {
+                R.Lv1 = load_list(C.nb, e1.nb_off, k, e1.big, e1.small, lane);
+                snap_point();
+                const u64 myH = mw_build<ROWS128>(rr, stride32, R.Lv1, k + 2, lane);
+                const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
+                const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);  // big->small, small->big
+                if (ab == ba) {
+                    if (!ab) R.sus |= 1u;   // table says adjacent, bitmap says not
+                } else {
+                    const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;
+                    cA = classify(myH, iv, iu);
+                    cB.P = cA.P; cB.S = cA.S;   // after the flip P and S are the same sets, M becomes {v->w, w->u}
+                    cB.M = (ab ? hk : hk1) & ballot((myH >> iv) & 1ull) & ~(3ull << k);
+                    fres = ab ? 1 : 2;
+                    if (extras_fit(cA, k + 2) && extras_fit(cB, k + 2)) { HA = HB = myH; kA = kB = k; nev = 2; }
+                    else go_wide = true;
+                }
+            } else {
+                go_wide = true;   // direction unknown yet: the wide run finds it
+            }
+            if (go_wide) {
+                if constexpr (!EXACT) {
+                    R.need_exact = 1u;
+                } else {
+                    fres = 0;
+                    if (k + 2 <= 64 * maxnw) {
+                        const Wide Wd = wide_carve(wide_lds, maxnw);
+                        wide_zero_counts(Wd, lane);
+                        const int res = wide_flip(Wd, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
+                        if (lane >= 2 && lane < 16 && lane - 1 <= tmax) R.myd = Wd.cnt[lane - 1];
+                        wave_sync();
+                        R.used_wide = 1u;
+                        if (res < 0) R.sus |= 1u;
+                        fres = res > 0 ? res : 0;
+                    } else {
+                        R.sus |= 1u;
+                    }
+                }
+            }
+            if (fres > 0 && !R.need_exact) {
+                R.nonempty = 1u;
+                const u32 cf = fres == 1 ? e1.big : e1.small, ct = fres == 1 ? e1.small : e1.big;
+                R.wid_clr = fres == 1 ? wid_bs : wid_sb; R.bit_clr = 1u << (ct & 31u);
+                R.wid_set = fres == 1 ? wid_sb : wid_bs; R.bit_set = 1u << (cf & 31u);
+                R.add_k = (u32)k; R.big_set = k + 2 > 48 ? 1u : 0u;
+            }
+        }
+    } else if (move == 1 && C.D > 0) {
+        // ---- double_edge_move (src/lib.rs:304-325)
+        R.dslot = (u32)idx;
+        FcmEdgeEntry e1 = {rdlane(tv, 8), rdlane(tv, 9), rdlane(tv, 10), rdlane(tv, 11)};            // the table's guess of the slot's pair
+        FcmEdgeEntry e2 = {rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};              // candidate 0's entry
+        // static loads first: the list of candidate 0
+        const u32 c0v = rdlane(tv, 12);
+        const bool c0ok = c0v != MW_NONE && (int)e2.k + 2 <= WAVE;
+        u32 Lv2pre = MW_NONE;
+        if (c0ok) Lv2pre = load_list(C.nb, e2.nb_off, (int)e2.k, e2.big, e2.small, lane);
+        snap_point();
+        // mutable state from here on: the slot's live entry first
+        u32 ed = C.dbl[R.dslot];
+        ed = mw_uni(ed);
+        if (ed != rdlane(tv, 1)) {   // the slot was rewritten since the table was filled (rare)
+            const FcmEdgeEntry t = C.etab[ed];
+            e1 = FcmEdgeEntry{mw_uni(t.big), mw_uni(t.small), mw_uni(t.nb_off), mw_uni(t.k)};
+        }
+        R.id1 = ed; R.big1 = e1.big; R.small1 = e1.small;
+        // single-edge candidates (:308-313): candidates 0 and 1 come from the table; a longer search, or a
+        // candidate that needs the wide path, is left to the exact run
+        u64 cand = 0ull, cand_next = 0ull;
+        bool found = false;
+        u32 rfwd = 0u;
+#pragma nounroll
+        for (int ci = 0; ci < (EXACT ? WAVE : 3) && !found && !R.need_exact; ++ci) {
+            if (ci < 2) {
+                const u32 cv = rdlane(tv, 12 + ci);
+                cand = cv == MW_NONE ? ~0ull : (u64)cv;
+                if (ci == 0) R.cx0 = cv; else R.cx1 = cv;
+            } else if constexpr (!EXACT) {
+                R.need_exact = 1u;
+                break;
+            } else if ((ci & 1) == 0) {  // Philox block sub = ci/2 + 1: two candidates
+                u32 v[4];
+                philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(ci >> 1) + 1u, (u32)seed, (u32)(seed >> 32), v);
+                cand = __umul64hi((u64)v[0] | ((u64)v[1] << 32), Mtot);
+                cand_next = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
+            } else {
+                cand = cand_next;
+            }
+            if (cand < U) {
+                if (ci > 0) {
+                    const FcmEdgeEntry t = C.etab[cand];
+                    e2 = FcmEdgeEntry{mw_uni(t.big), mw_uni(t.small), mw_uni(t.nb_off), mw_uni(t.k)};
+                }
+                const int ck = (int)e2.k;
+                u32 f = 0u, bwd = 0u;
+                if (ck + 2 <= WAVE) {
+                    if (ci == 0) {
+                        R.Lv2 = Lv2pre;
+                    } else {
+                        R.Lv2 = load_list(C.nb, e2.nb_off, ck, e2.big, e2.small, lane);
+                    }
+                    HB = mw_build<ROWS128>(rr, stride32, R.Lv2, ck + 2, lane);
+                    f = (u32)(rdlane64(HB, ck + 1) >> ck) & 1u;
+                    bwd = (u32)(rdlane64(HB, ck) >> (ck + 1)) & 1u;
+                } else {
+                    if constexpr (!EXACT) {
+                        R.need_exact = 1u;
+                        break;
+                    } else {  // wide candidate: look at its two words directly
+                        const u32 wf = mw_uni(C.rows[e2.big * stride32 + (e2.small >> 5)]), wb = mw_uni(C.rows[e2.small * stride32 + (e2.big >> 5)]);
+                        f = (wf >> (e2.small & 31u)) & 1u;
+                        bwd = (wb >> (e2.big & 31u)) & 1u;
+                        R.Lv2 = MW_NONE;
+                    }
+                }
+                if (!(f | bwd)) R.sus |= 1u;
+                found = (f ^ bwd) != 0u;
+                rfwd = f;
+            }
+        }
+        if (found) {
+            const int dk = (int)e1.k, rk = (int)e2.k;
+            R.id2 = (u32)cand; R.big2 = e2.big; R.small2 = e2.small;
+            const u32 ea = rfwd ? e2.big : e2.small, eb = rfwd ? e2.small : e2.big;  // ea->eb is the single edge
+            const u32 dfrom = coin ? e1.big : e1.small, dto = coin ? e1.small : e1.big;  // delme (:316-320)
+            go_wide = dk + 2 > WAVE || rk + 2 > WAVE;
+            bool okd = true;
+            if (!go_wide) {
+                R.Lv1 = load_list(C.nb, e1.nb_off, dk, e1.big, e1.small, lane);
+                HA = mw_build<ROWS128>(rr, stride32, R.Lv1, dk + 2, lane);
+                // (1) remove the direction the coin picks from the reciprocal pair
+                const u32 ab = (u32)((rdlane64(HA, dk + 1) >> dk) & 1ull), ba = (u32)((rdlane64(HA, dk) >> (dk + 1)) & 1ull);
+                okd = (ab & ba) != 0u;
+                const int iu = coin ? dk : dk + 1, iv = coin ? dk + 1 : dk;
+                cA = classify(HA, iv, iu);
+                // (2) add the reverse of the single edge on the graph without the removed one
+                const u64 mf = ballot(lane < rk + 2 && R.Lv2 == dfrom), mt = ballot(lane < rk + 2 && R.Lv2 == dto);
+                if (mf && mt) {
+                    const int fi = __ffsll((long long)mf) - 1, tix = __ffsll((long long)mt) - 1;
+                    if (lane == tix) HB &= ~(1ull << fi);
+                }
+                const int ia = rfwd ? rk : rk + 1, ib = rfwd ? rk + 1 : rk;  // a->b exists, add b->a
+                if (lane == ia) HB |= 1ull << ib;
+                cB = classify(HB, ia, ib);
+                if (extras_fit(cA, dk + 2) && extras_fit(cB, rk + 2)) { kA = dk; kB = rk; nev = 2; }
+                else go_wide = true;
+            }
+            if (go_wide) {
+                if constexpr (!EXACT) {
+                    R.need_exact = 1u;
+                } else if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
+                    R.sus |= 1u;
+                } else {
+                    const Wide Wd = wide_carve(wide_lds, maxnw);
+                    wide_zero_counts(Wd, lane);
+                    okd = wide_del(Wd, C.rows, stride32, C.nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
+                    wide_add(Wd, C.rows, stride32, C.nb, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax);
+                    if (lane >= 2 && lane < 16 && lane - 1 <= tmax) R.myd = Wd.cnt[lane - 1];
+                    wave_sync();
+                    R.used_wide = 1u;
+                }
+            }
+            if (!okd) R.sus |= 2u;  // slot list says reciprocal, bitmap says not
+            R.nonempty = 1u; R.is_dmove = 1u;
+            R.wid_clr = dfrom * stride32 + (dto >> 5); R.bit_clr = 1u << (dto & 31u);
+            R.wid_set = eb * stride32 + (ea >> 5); R.bit_set = 1u << (ea & 31u);
+            R.dnew = (u32)cand;
+            R.add_k = (u32)(dk + rk); R.big_set = (dk + 2 > 48 || rk + 2 > 48) ? 1u : 0u;
+        }
+    }
+    snap_point();   // (paths without a load of mutable state)
+    if (R.nonempty) {   // the two bitmap words a commit rewrites, read now: the commit is then two plain stores
+        R.w_clr = C.rows[R.wid_clr];
+        R.w_set = C.rows[R.wid_set];
+    }
+    if (nev) {
+        int delta[MAXT + 1];
+#pragma unroll
+        for (int t = 0; t <= MAXT; ++t) delta[t] = 0;
+#pragma nounroll
+        for (int ev = 0; ev < 2; ++ev) {
+            const Cls c = ev ? cB : cA;
+            eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta);
+        }
+#pragma unroll
+        for (int tq = 1; tq <= MAXT; ++tq) {
+            const int sum = wave_sum_i32(delta[tq]);
+            if (lane == tq + 1) R.myd = (long long)sum;
+        }
+    }
+}
+
+// ---- out of line: the exact run.  Context from LDS, result to the wave's LDS (MX_*, myd behind it).
+template <int MAXT, bool ROWS128>
+__device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 tv, u32 q)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    wv = mw_uni(wv); q = mw_uni(q);
+    const u32 *ctx = (const u32 *)(smem + MW_CTX_OFF);
+    const u32 cv = lane < MC_WORDS ? ctx[lane] : 0u;
+    const u32 W = rdlane(cv, MC_W);
+    const int maxnw = (int)rdlane(cv, MC_MAXNW);
+    const MwChain C = mw_chain_from_lds(ctx, lane);
+    u64 *mine_lds = smem + MW_SHARED_WORDS + 12u * W + (size_t)wv * MW_WAVE_WORDS;
+    u64 *wide_lds = smem + MW_SHARED_WORDS + 12u * W + (size_t)W * MW_WAVE_WORDS;
+    const u64 seed = (u64)rdlane(cv, MC_SEED) | ((u64)rdlane(cv, MC_SEED + 1) << 32);
+    const u64 sampled0 = (u64)rdlane(cv, MC_SAMPLED0) | ((u64)rdlane(cv, MC_SAMPLED0 + 1) << 32);
+    MwProp R;
+    mw_run<MAXT, ROWS128, true>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, R);
+    u32 *out = (u32 *)(mine_lds + 64);
+    if (lane == 0) {
+        out[MX_FLAGS] = (R.nonempty ? MXF_NONEMPTY : 0u) | (R.is_dmove ? MXF_DMOVE : 0u) | (R.used_wide ? MXF_WIDE : 0u) | (R.big_set ? MXF_BIG : 0u);
+        out[MX_WCLR] = R.wid_clr; out[MX_WSET] = R.wid_set; out[MX_BCLR] = R.bit_clr; out[MX_BSET] = R.bit_set;
+        out[MX_OCLR] = R.w_clr; out[MX_OSET] = R.w_set; out[MX_DSLOT] = R.dslot; out[MX_DNEW] = R.dnew; out[MX_ADDK] = R.add_k;
+        out[MX_ID1] = R.id1; out[MX_BIG1] = R.big1; out[MX_SMALL1] = R.small1;
+        out[MX_ID2] = R.id2; out[MX_BIG2] = R.big2; out[MX_SMALL2] = R.small2; out[MX_SUS] = R.sus;
+    }
+    if (lane < 16) ((long long *)(out + MX_WORDS))[lane] = R.myd;
+    wave_sync();
+}
+
+// ---- out of line: the wave's next 32 draws.  Lane j draws the wave's j-th proposal from q on ("Philox per lane"),
+// with the static data it names.
+__device__ __attribute__((noinline)) void mw_fill_table(u64 *smem, u32 wv, u32 q)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    wv = mw_uni(wv); q = mw_uni(q);
+    const u32 *ctx = (const u32 *)(smem + MW_CTX_OFF);
+    const u32 cv = lane < MC_WORDS ? ctx[lane] : 0u;
+    const u32 W = rdlane(cv, MC_W);
+    const MwChain C = mw_chain_from_lds(ctx, lane);
+    u32 *T = (u32 *)(smem + MW_SHARED_WORDS + 12u * W + (size_t)wv * MW_WAVE_WORDS + 128);
+    const u64 seed = (u64)rdlane(cv, MC_SEED) | ((u64)rdlane(cv, MC_SEED + 1) << 32);
+    const u64 sampled0 = (u64)rdlane(cv, MC_SAMPLED0) | ((u64)rdlane(cv, MC_SAMPLED0 + 1) << 32);
+    const u64 cum0 = (u64)rdlane(cv, MC_CUM0) | ((u64)rdlane(cv, MC_CUM0 + 1) << 32);
+    const u64 cum1 = (u64)rdlane(cv, MC_CUM1) | ((u64)rdlane(cv, MC_CUM1 + 1) << 32);
+    const u64 cum2 = (u64)rdlane(cv, MC_CUM2) | ((u64)rdlane(cv, MC_CUM2 + 1) << 32);
+    const u32 gchain = rdlane(cv, MC_GCHAIN), U = C.U, D = C.D;
+    const u64 Mtot = (u64)U + D;
+    const int j = lane & 31;
+    const u64 tj = sampled0 + (u64)q + (u64)j * W;
+    const u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+    u32 w[4];
+    philox4x32_10((u32)tj, (u32)(tj >> 32), gchain, 0u, k0, k1, w);
+    const int mv = ((u64)w[0] < cum0) ? 0 : (((u64)w[0] < cum1) ? 1 : (((u64)w[0] < cum2) ? 2 : 3));
+    const u64 x64 = (u64)w[2] | ((u64)w[3] << 32);
+    const u64 ix = mv >= 2 ? x64 : __umul64hi(x64, mv == 0 ? Mtot : (u64)D);
+    FcmEdgeEntry e = {0u, 0u, 0u, 0u}, de = {0u, 0u, 0u, 0u};
+    u32 ed = 0u, c0 = MW_NONE, c1 = MW_NONE;
+    if (mv == 0 && ix < U) e = C.etab[ix];
+    if (mv == 1 && D > 0) {
+        ed = C.dbl[(u32)ix];           // a guess (the list is mutable): verified when the proposal runs
+        de = C.etab[ed];
+        u32 v[4];
+        philox4x32_10((u32)tj, (u32)(tj >> 32), gchain, 1u, k0, k1, v);
+        const u64 x0 = __umul64hi((u64)v[0] | ((u64)v[1] << 32), Mtot), x1 = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
+        if (x0 < U) { c0 = (u32)x0; e = C.etab[x0]; }
+        if (x1 < U) c1 = (u32)x1;
+    }
+    if (lane < 32) {
+        u32 *t = T + j * MW_TBL_WORDS;
+        t[0] = (u32)mv | ((w[1] & 1u) << 8); t[1] = ed; t[2] = (u32)ix; t[3] = (u32)(ix >> 32);
+        t[4] = e.big; t[5] = e.small; t[6] = e.nb_off; t[7] = e.k;
+        t[8] = de.big; t[9] = de.small; t[10] = de.nb_off; t[11] = de.k;
+        t[12] = c0; t[13] = c1;
+    }
+    wave_sync();
+}
+
 template <int MAXT, bool ROWS128>
 __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 {
@@ -80,30 +473,28 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
     const int lane = threadIdx.x & (WAVE - 1);
     const u32 wv = mw_uni(threadIdx.x >> 6);
     const u32 chain = blockIdx.x;
-    const int tmax = MAXT;
     const u32 N = (u32)p.nprop;                            // <= FCM_LAUNCH_CHUNK per launch
     if (N == 0) return;
 
     u64 *cntL = smem;
-    u64 *bminL = smem + 16, *bmaxL = smem + 32;
-    u32 *ctl = (u32 *)(smem + 48);                         // [0] head  [1] state inside the bounds?
+    u64 *bminL = smem + 8, *bmaxL = smem + 16;
+    u32 *ctl = (u32 *)(smem + 24);                         // [0] head  [1] state inside the bounds?
+    u32 *ctx = (u32 *)(smem + MW_CTX_OFF);
+    u32 *vis = (u32 *)(smem + MW_VIS_OFF);                 // [w]: every proposal of wave w below this index is in memory
     u32 *logL = (u32 *)(smem + MW_SHARED_WORDS);
+    const u32 ring = 2u * W - 1u;                          // log ring mask
     const int maxnw = p.maxnw < 2 ? 2 : p.maxnw;
-    u64 *mine_lds = smem + MW_SHARED_WORDS + 6u * W + (size_t)wv * MW_WAVE_WORDS;
+    u64 *mine_lds = smem + MW_SHARED_WORDS + 12u * W + (size_t)wv * MW_WAVE_WORDS;
     u64 *Hp = mine_lds;                                    // split graph + arc list (eval_nodes / walk_nodes)
-    u32 *T = (u32 *)(mine_lds + 128);                      // this wave's next 32 proposals
-    u64 *wide_lds = smem + MW_SHARED_WORDS + 6u * W + (size_t)W * MW_WAVE_WORDS;
-
-    u32 *rows = p.rows + (size_t)chain * p.rows_per_chain;
-    const u64 rows_bytes = p.rows_per_chain * 4ull;
-    u32 *dbl = p.dbl + (size_t)chain * p.dbl_stride;
+    const u32 *T = (const u32 *)(mine_lds + 128);          // this wave's next 32 proposals
     u64 *st_g = (u64 *)p.stats + (size_t)chain * FCM_DEV_NSTATS;
-    const u32 *nb = p.nb;
-    const FcmEdgeEntry *etab = p.etab;
-    const u32 U = p.U, D = p.D, stride32 = p.stride32;
-    const u64 Mtot = (u64)U + D;
-    const u32 gchain = p.first_chain + chain;
-    const u64 sampled0 = st_g[0];                          // Philox step index of proposal 0 of this launch
+
+    MwChain C;
+    C.rows = p.rows + (size_t)chain * p.rows_per_chain;
+    C.dbl = p.dbl + (size_t)chain * p.dbl_stride;
+    C.nb = p.nb; C.etab = p.etab;
+    C.rows_bytes = p.rows_per_chain * 4ull;
+    C.U = p.U; C.D = p.D; C.stride32 = p.stride32;
 
     if (wv == 0) {
         const int NC = p.ncounts;
@@ -111,349 +502,179 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         u64 *cnt_g = (u64 *)p.counts + (size_t)chain * FCM_DEV_MAX_COUNTS;
         const u64 c0 = cl ? cnt_g[lane] : 0ull;
         const u64 mn = cl ? p.bmin[lane] : 0ull, mx = cl ? p.bmax[lane] : ~0ull;   // zero-padded (src/util.rs:53-57)
-        if (lane < 16) { cntL[lane] = c0; bminL[lane] = mn; bmaxL[lane] = mx; }
+        if (lane < 8) { cntL[lane] = c0; bminL[lane] = mn; bmaxL[lane] = mx; }
+        if (lane < 16) vis[lane] = lane < (int)W ? (u32)lane : MW_NONE;
         const bool inb = ballot(cl && (c0 < mn || c0 > mx)) == 0ull;
-        if (lane == 0) { ctl[0] = 0u; ctl[1] = inb ? 1u : 0u; }
+        if (lane == 0) {
+            ctl[0] = 0u; ctl[1] = inb ? 1u : 0u;
+            *(u64 *)(ctx + MC_ROWS) = (u64)C.rows; *(u64 *)(ctx + MC_DBL) = (u64)C.dbl; *(u64 *)(ctx + MC_NB) = (u64)C.nb;
+            *(u64 *)(ctx + MC_ETAB) = (u64)C.etab; *(u64 *)(ctx + MC_ROWS_BYTES) = C.rows_bytes; *(u64 *)(ctx + MC_SEED) = p.seed;
+            *(u64 *)(ctx + MC_SAMPLED0) = st_g[0];         // Philox step index of proposal 0 of this launch
+            *(u64 *)(ctx + MC_CUM0) = p.cum0; *(u64 *)(ctx + MC_CUM1) = p.cum1; *(u64 *)(ctx + MC_CUM2) = p.cum2;
+            ctx[MC_U] = C.U; ctx[MC_D] = C.D; ctx[MC_STRIDE32] = C.stride32; ctx[MC_GCHAIN] = p.first_chain + chain;
+            ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = W;
+        }
     }
     mw_barrier();
 
     // this wave's share of the counters (added to the stats row at the end)
-    u32 accepted = 0, n_empty = 0, n_flip = 0, n_dmove = 0, sum_k = 0, n_redo = 0, n_wide = 0, n_big = 0, mine = 0;
+    u32 accepted = 0, n_empty = 0, n_dmove = 0, sum_k = 0, n_redo = 0, n_wide = 0, n_big = 0, mine = 0;
     u32 count_len = 0u, status = 0u;
     u32 ti = 32u;                                          // next table entry; 32 = refill
 
+#ifdef MW_STAMP
+    u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MW_T(x) const u64 x = __builtin_amdgcn_s_memtime()
+#else
+#define MW_T(x) do { } while (0)
+#endif
+    const int lane_id = lane;
     for (u32 q = wv; q < N; q += W) {
-        // ---- draw table: lane j draws this wave's j-th proposal from here ("Philox per lane"), with the static data it names
+        MW_T(t_start);
+        // (a fresh copy of the lane id per proposal: comparisons with it are recomputed where they are used -- one VALU each --
+        // instead of being hoisted out of the loop into SGPR pairs that are then spilled and reloaded)
+        int lane = lane_id;
+        // asm volatile("" : "+v"(lane));
         if (ti >= 32u) {
-            const int j = lane & 31;
-            const u64 tj = sampled0 + (u64)q + (u64)j * W;
-            const u32 k0 = (u32)p.seed, k1 = (u32)(p.seed >> 32);
-            u32 w[4];
-            philox4x32_10((u32)tj, (u32)(tj >> 32), gchain, 0u, k0, k1, w);
-            const u64 cum0 = p.cum0, cum1 = p.cum1, cum2 = p.cum2;
-            const int mv = ((u64)w[0] < cum0) ? 0 : (((u64)w[0] < cum1) ? 1 : (((u64)w[0] < cum2) ? 2 : 3));
-            const u64 x64 = (u64)w[2] | ((u64)w[3] << 32);
-            const u64 ix = mv >= 2 ? x64 : __umul64hi(x64, mv == 0 ? Mtot : (u64)D);
-            FcmEdgeEntry e = {0u, 0u, 0u, 0u}, de = {0u, 0u, 0u, 0u};
-            u32 ed = 0u, c0 = MW_NONE, c1 = MW_NONE;
-            if (mv == 0 && ix < U) e = etab[ix];
-            if (mv == 1 && D > 0) {
-                ed = dbl[(u32)ix];           // a guess (the list is mutable): verified when the proposal runs
-                de = etab[ed];
-                u32 v[4];
-                philox4x32_10((u32)tj, (u32)(tj >> 32), gchain, 1u, k0, k1, v);
-                const u64 x0 = __umul64hi((u64)v[0] | ((u64)v[1] << 32), Mtot), x1 = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
-                if (x0 < U) { c0 = (u32)x0; e = etab[x0]; }
-                if (x1 < U) c1 = (u32)x1;
-            }
-            if (lane < 32) {
-                u32 *t = T + j * MW_TBL_WORDS;
-                t[0] = (u32)mv | ((w[1] & 1u) << 8); t[1] = ed; t[2] = (u32)ix; t[3] = (u32)(ix >> 32);
-                t[4] = e.big; t[5] = e.small; t[6] = e.nb_off; t[7] = e.k;
-                t[8] = de.big; t[9] = de.small; t[10] = de.nb_off; t[11] = de.k;
-                t[12] = c0; t[13] = c1;
-            }
-            wave_sync();
+            mw_fill_table(smem, wv, q);
             ti = 0u;
         }
         const u32 tv = lane < (int)MW_TBL_WORDS ? T[ti * MW_TBL_WORDS + lane] : 0u;
         ++ti;
-        const int move = (int)(rdlane(tv, 0) & 0xFFu);
-        const u32 coin = (rdlane(tv, 0) >> 8) & 1u;
-        const u64 idx = (u64)rdlane(tv, 2) | ((u64)rdlane(tv, 3) << 32);
-        if (move >= 2) status |= 4u;   // this kernel has no clique moves
+        if ((rdlane(tv, 0) & 0xFFu) >= 2u) status |= 4u;   // this kernel has no clique moves
 
-        // ---- the proposal: first on the state as committed now, again under the token if that was not good enough
-        bool exact = false;
-        u32 nonempty, is_dmove, used_wide, big_set;   // 0 / 1 (wave-uniform integers: they end up in SGPRs, not in lane masks)
-        u32 wid_clr, wid_set, bit_clr, bit_set, w_clr, w_set, dslot, dnew, add_k;
-        u32 id1, big1, small1, id2, big2, small2, cx0, cx1, sus;
-        u32 Lv1, Lv2;
-        long long myd;
+        // ---- the proposal on the state as committed now.  Commits below snap are visible to every load from here on;
+        // those from snap on are held against this proposal's reads before it is decided.
+        MwProp R;
+        MW_T(t_snap);
+        mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, R, vis, wv, q, W);
+        const u32 snap = R.snap;
+        MW_T(t_run);
+
+        // ---- before the token: everything the decision can have ready
+        u32 *stage = (u32 *)(mine_lds + 64);               // (the arc list's place: free between evaluations)
+        mw_stage(stage, R, lane);
+        // the commit's two stores (one value twice if both changes fall into one word: double-edge move only)
+        u32 nclr = R.w_clr & ~R.bit_clr, nset = R.w_set | R.bit_set;
+        if (R.wid_clr == R.wid_set) { nclr |= R.bit_set; nset = nclr; }
+
+        // ---- in-order decision.  While waiting for the token, look at the decisions taken since `snap` as they are
+        // published: by the time head == q only the last of them is left.
+        bool hit = R.need_exact != 0u;
+        u32 c = snap;
         for (;;) {
-            nonempty = 0u; is_dmove = 0u; used_wide = 0u; big_set = 0u;
-            wid_clr = wid_set = MW_NONE; bit_clr = bit_set = 0u; w_clr = w_set = 0u; dslot = MW_NONE; dnew = 0u; add_k = 0u;
-            id1 = big1 = small1 = id2 = big2 = small2 = cx0 = cx1 = MW_NONE; sus = 0u;
-            Lv1 = MW_NONE; Lv2 = MW_NONE;
-            myd = 0;
-            bool need_exact = false;
-            // commits below snap are visible to every load from here on; those from snap on are checked under the token
-            const u32 snap = exact ? q : mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-            const rsrc_t rr = make_rows_rsrc(rows, rows_bytes);
-
-            // what is to be evaluated: up to two (masks, classes, size, sign) on the fast path
-            int nev = 0;
-            u64 HA = 0ull, HB = 0ull;
-            Cls cA = {0ull, 0ull, 0ull}, cB = {0ull, 0ull, 0ull};
-            int kA = 0, kB = 0;
-            bool go_wide = false;
-            // the pairs of the move: (big1, small1) with local set 1, (big2, small2) with local set 2
-            FcmEdgeEntry e1 = {0u, 0u, 0u, 0u}, e2 = {0u, 0u, 0u, 0u};
-            u32 rfwd = 0u;
-            int fres = 0;          // flip: 1 = big->small flipped, 2 = small->big
-
-            if (move == 0) {
-                // ---- single_edge_flip (src/lib.rs:292-299)
-                if (Mtot > 0 && idx < U) {
-                    e1 = FcmEdgeEntry{rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};
-                    const int k = (int)e1.k;
-                    id1 = (u32)idx; big1 = e1.big; small1 = e1.small;
-                    if (k + 2 <= WAVE) {
-                        Lv1 = load_list(nb, e1.nb_off, k, e1.big, e1.small, lane);
-                        const u64 myH = mw_build<ROWS128>(rr, stride32, Lv1, k + 2, lane);
-                        const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
-                        const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);  // big->small, small->big
-                        if (ab == ba) {
-                            if (!ab) sus |= 1u;   // table says adjacent, bitmap says not
-                        } else {
-                            const int iu = ab ? k : k + 1, iv = ab ? k + 1 : k;
-                            cA = classify(myH, iv, iu);
-                            cB.P = cA.P; cB.S = cA.S;   // after the flip P and S are the same sets, M becomes {v->w, w->u}
-                            cB.M = (ab ? hk : hk1) & ballot((myH >> iv) & 1ull) & ~(3ull << k);
-                            fres = ab ? 1 : 2;
-                            if (extras_fit(cA, k + 2) && extras_fit(cB, k + 2)) { HA = HB = myH; kA = kB = k; nev = 2; }
-                            else go_wide = true;
-                        }
-                    } else {
-                        go_wide = true;   // direction unknown yet: the wide run finds it
-                    }
-                    if (go_wide) {
-                        if (!exact) {
-                            need_exact = true;
-                        } else if (k + 2 <= 64 * maxnw) {
-                            const Wide Wd = wide_carve(wide_lds, maxnw);
-                            wide_zero_counts(Wd, lane);
-                            const int res = wide_flip(Wd, rows, stride32, nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
-                            if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = Wd.cnt[lane - 1];
-                            wave_sync();
-                            used_wide = 1u;
-                            if (res < 0) sus |= 1u;
-                            fres = res > 0 ? res : 0;
-                        } else {
-                            sus |= 1u;
-                        }
-                    }
-                    if (fres > 0 && !need_exact) {
-                        nonempty = 1u;
-                        const u32 cf = fres == 1 ? e1.big : e1.small, ct = fres == 1 ? e1.small : e1.big;
-                        wid_clr = cf * stride32 + (ct >> 5); bit_clr = 1u << (ct & 31u);
-                        wid_set = ct * stride32 + (cf >> 5); bit_set = 1u << (cf & 31u);
-                        add_k = (u32)k; big_set = k + 2 > 48 ? 1u : 0u;
-                    }
-                }
-            } else if (move == 1 && D > 0) {
-                // ---- double_edge_move (src/lib.rs:304-325)
-                dslot = (u32)idx;
-                const u32 ed = mw_uni(dbl[dslot]);                                             // the live entry ...
-                e1 = FcmEdgeEntry{rdlane(tv, 8), rdlane(tv, 9), rdlane(tv, 10), rdlane(tv, 11)};   // ... and the table's guess of its pair
-                if (ed != rdlane(tv, 1)) {
-                    const FcmEdgeEntry t = etab[ed];
-                    e1 = FcmEdgeEntry{mw_uni(t.big), mw_uni(t.small), mw_uni(t.nb_off), mw_uni(t.k)};
-                }
-                id1 = ed; big1 = e1.big; small1 = e1.small;
-                // single-edge candidates (:308-313): candidates 0 and 1 come from the table; a longer search, or a
-                // candidate that needs the wide path, is left to the exact run
-                e2 = FcmEdgeEntry{rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};
-                u64 cand = 0ull, cand_next = 0ull;
-                bool found = false;
-                const u64 tt = sampled0 + q;
-#pragma nounroll
-                for (int ci = 0; ci < WAVE && !found && !need_exact; ++ci) {
-                    if (ci < 2) {
-                        const u32 cv = rdlane(tv, 12 + ci);
-                        cand = cv == MW_NONE ? ~0ull : (u64)cv;
-                        if (ci == 0) cx0 = cv; else cx1 = cv;
-                    } else if (!exact) {
-                        need_exact = true;
-                        break;
-                    } else if ((ci & 1) == 0) {  // Philox block sub = ci/2 + 1: two candidates
-                        u32 v[4];
-                        philox4x32_10((u32)tt, (u32)(tt >> 32), gchain, (u32)(ci >> 1) + 1u, (u32)p.seed, (u32)(p.seed >> 32), v);
-                        cand = __umul64hi((u64)v[0] | ((u64)v[1] << 32), Mtot);
-                        cand_next = __umul64hi((u64)v[2] | ((u64)v[3] << 32), Mtot);
-                    } else {
-                        cand = cand_next;
-                    }
-                    if (cand < U) {
-                        if (ci > 0) {
-                            const FcmEdgeEntry t = etab[cand];
-                            e2 = FcmEdgeEntry{mw_uni(t.big), mw_uni(t.small), mw_uni(t.nb_off), mw_uni(t.k)};
-                        }
-                        const int ck = (int)e2.k;
-                        u32 f, bwd;
-                        if (ck + 2 <= WAVE) {
-                            Lv2 = load_list(nb, e2.nb_off, ck, e2.big, e2.small, lane);
-                            HB = mw_build<ROWS128>(rr, stride32, Lv2, ck + 2, lane);
-                            f = (u32)(rdlane64(HB, ck + 1) >> ck) & 1u;
-                            bwd = (u32)(rdlane64(HB, ck) >> (ck + 1)) & 1u;
-                        } else if (!exact) {
-                            need_exact = true;
-                            break;
-                        } else {  // wide candidate: look at its two words directly
-                            const u32 wf = mw_uni(rows[(size_t)e2.big * stride32 + (e2.small >> 5)]);
-                            const u32 wb = mw_uni(rows[(size_t)e2.small * stride32 + (e2.big >> 5)]);
-                            f = (wf >> (e2.small & 31u)) & 1u;
-                            bwd = (wb >> (e2.big & 31u)) & 1u;
-                            Lv2 = MW_NONE;
-                        }
-                        if (!(f | bwd)) sus |= 1u;
-                        found = (f ^ bwd) != 0u;
-                        rfwd = f;
-                    }
-                }
-                if (found) {
-                    const int dk = (int)e1.k, rk = (int)e2.k;
-                    id2 = (u32)cand; big2 = e2.big; small2 = e2.small;
-                    const u32 ea = rfwd ? e2.big : e2.small, eb = rfwd ? e2.small : e2.big;  // ea->eb is the single edge
-                    const u32 dfrom = coin ? e1.big : e1.small, dto = coin ? e1.small : e1.big;  // delme (:316-320)
-                    go_wide = dk + 2 > WAVE || rk + 2 > WAVE;
-                    bool okd = true;
-                    if (!go_wide) {
-                        Lv1 = load_list(nb, e1.nb_off, dk, e1.big, e1.small, lane);
-                        HA = mw_build<ROWS128>(rr, stride32, Lv1, dk + 2, lane);
-                        // (1) remove the direction the coin picks from the reciprocal pair
-                        const u32 ab = (u32)((rdlane64(HA, dk + 1) >> dk) & 1ull), ba = (u32)((rdlane64(HA, dk) >> (dk + 1)) & 1ull);
-                        okd = (ab & ba) != 0u;
-                        const int iu = coin ? dk : dk + 1, iv = coin ? dk + 1 : dk;
-                        cA = classify(HA, iv, iu);
-                        // (2) add the reverse of the single edge on the graph without the removed one
-                        const u64 mf = ballot(lane < rk + 2 && Lv2 == dfrom), mt = ballot(lane < rk + 2 && Lv2 == dto);
-                        if (mf && mt) {
-                            const int fi = __ffsll((long long)mf) - 1, tix = __ffsll((long long)mt) - 1;
-                            if (lane == tix) HB &= ~(1ull << fi);
-                        }
-                        const int ia = rfwd ? rk : rk + 1, ib = rfwd ? rk + 1 : rk;  // a->b exists, add b->a
-                        if (lane == ia) HB |= 1ull << ib;
-                        cB = classify(HB, ia, ib);
-                        if (extras_fit(cA, dk + 2) && extras_fit(cB, rk + 2)) { kA = dk; kB = rk; nev = 2; }
-                        else go_wide = true;
-                    }
-                    if (go_wide) {
-                        if (!exact) {
-                            need_exact = true;
-                        } else if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
-                            sus |= 1u;
-                        } else {
-                            const Wide Wd = wide_carve(wide_lds, maxnw);
-                            wide_zero_counts(Wd, lane);
-                            okd = wide_del(Wd, rows, stride32, nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
-                            wide_add(Wd, rows, stride32, nb, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax);
-                            if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = Wd.cnt[lane - 1];
-                            wave_sync();
-                            used_wide = 1u;
-                        }
-                    }
-                    if (!okd) sus |= 2u;  // slot list says reciprocal, bitmap says not
-                    nonempty = 1u; is_dmove = 1u;
-                    wid_clr = dfrom * stride32 + (dto >> 5); bit_clr = 1u << (dto & 31u);
-                    wid_set = eb * stride32 + (ea >> 5); bit_set = 1u << (ea & 31u);
-                    dnew = (u32)cand;
-                    add_k = (u32)(dk + rk); big_set = (dk + 2 > 48 || rk + 2 > 48) ? 1u : 0u;
+            const u32 h = mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // h <= q
+            while (c < h && !hit) {
+                const u32 ev = lane < ML_WORDS ? logL[(c & ring) * ML_WORDS + lane] : 0u;
+                ++c;
+                const u32 fl = rdlane(ev, ML_FLAGS);
+                if (!(fl & ML_ACCEPTED)) continue;
+                const u32 b1 = rdlane(ev, ML_BIG1), s1 = rdlane(ev, ML_SMALL1), i1 = rdlane(ev, ML_ID1);
+                const u32 wc = rdlane(ev, ML_WCLR), ws = rdlane(ev, ML_WSET);
+                hit = mw_inside(R.Lv1, b1, s1) || mw_inside(R.Lv2, b1, s1) || i1 == R.cx0 || i1 == R.cx1
+                      || wc == R.wid_clr || wc == R.wid_set || ws == R.wid_clr || ws == R.wid_set;
+                if (fl & ML_DMOVE) {
+                    const u32 b2 = rdlane(ev, ML_BIG2), s2 = rdlane(ev, ML_SMALL2), i2 = rdlane(ev, ML_ID2);
+                    hit = hit || mw_inside(R.Lv1, b2, s2) || mw_inside(R.Lv2, b2, s2) || i2 == R.cx0 || i2 == R.cx1 || rdlane(ev, ML_DSLOT) == R.dslot;
                 }
             }
-            if (nonempty) {   // the two bitmap words a commit rewrites, read now: the commit is then two plain stores
-                w_clr = rows[wid_clr];
-                w_set = rows[wid_set];
-            }
-            if (nev) {
-                int delta[MAXT + 1];
-#pragma unroll
-                for (int t = 0; t <= MAXT; ++t) delta[t] = 0;
-#pragma nounroll
-                for (int ev = 0; ev < 2; ++ev) {
-                    const Cls c = ev ? cB : cA;
-                    eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta);
-                }
-#pragma unroll
-                for (int tq = 1; tq <= MAXT; ++tq) {
-                    const int sum = wave_sum_i32(delta[tq]);
-                    if (lane == tq + 1) myd = (long long)sum;
-                }
-            }
-            if (exact) break;
-
-            // ---- in-order decision.  While waiting for the token, hold the decisions taken since `snap` against this
-            // proposal's reads as they are published: by the time head == q only the last of them is left to look at.
-            bool hit = need_exact;
-            u32 c = snap;
-            for (;;) {
-                const u32 h = mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // h <= q
-                while (c < h && !hit) {
-                    const u32 ev = lane < ML_WORDS ? logL[(c & (W - 1u)) * ML_WORDS + lane] : 0u;
-                    ++c;
-                    const u32 fl = rdlane(ev, ML_FLAGS);
-                    if (!(fl & ML_ACCEPTED)) continue;
-                    const u32 b1 = rdlane(ev, ML_BIG1), s1 = rdlane(ev, ML_SMALL1), i1 = rdlane(ev, ML_ID1);
-                    const u32 wc = rdlane(ev, ML_WCLR), ws = rdlane(ev, ML_WSET);
-                    hit = mw_inside(Lv1, b1, s1) || mw_inside(Lv2, b1, s1) || i1 == cx0 || i1 == cx1
-                          || wc == wid_clr || wc == wid_set || ws == wid_clr || ws == wid_set;
-                    if (fl & ML_DMOVE) {
-                        const u32 b2 = rdlane(ev, ML_BIG2), s2 = rdlane(ev, ML_SMALL2), i2 = rdlane(ev, ML_ID2);
-                        hit = hit || mw_inside(Lv1, b2, s2) || mw_inside(Lv2, b2, s2) || i2 == cx0 || i2 == cx1 || rdlane(ev, ML_DSLOT) == dslot;
-                    }
-                }
-                if (h == q) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!hit) break;
-            exact = true;   // under the token: every earlier commit is visible, nobody else can commit
-            n_redo += 1;
+            if (h == q) break;
+#ifdef MW_STAMP
+            st_acc[7] += 1;
+#endif
+            // not yet: doze by how far off the token is (a decision takes several hundred cycles)
+            const u32 dist = q - h;
+            if (dist >= 4u) __builtin_amdgcn_s_sleep(10);
+            else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
+            else __builtin_amdgcn_s_sleep(1);
+        }
+        MW_T(t_token);
+        if (hit) {
+            // under the token nobody else can commit; once every earlier commit is in memory too, run it again, all of it
+            n_redo += 1u;
+            while (mw_vis_min(vis, W, lane) < q) __builtin_amdgcn_s_sleep(1);
+            mw_exact_call<MAXT, ROWS128>(smem, wv, tv, q);
+            const u32 *out = (const u32 *)(mine_lds + 64);
+            const u32 xv = lane < MX_WORDS ? out[lane] : 0u;
+            if (lane < 16) R.myd = ((const long long *)(out + MX_WORDS))[lane];
+            const u32 fl = rdlane(xv, MX_FLAGS);
+            R.nonempty = fl & 1u; R.is_dmove = (fl >> 1) & 1u; R.used_wide = (fl >> 2) & 1u; R.big_set = (fl >> 3) & 1u;
+            R.wid_clr = rdlane(xv, MX_WCLR); R.wid_set = rdlane(xv, MX_WSET); R.bit_clr = rdlane(xv, MX_BCLR); R.bit_set = rdlane(xv, MX_BSET);
+            R.w_clr = rdlane(xv, MX_OCLR); R.w_set = rdlane(xv, MX_OSET); R.dslot = rdlane(xv, MX_DSLOT); R.dnew = rdlane(xv, MX_DNEW);
+            R.add_k = rdlane(xv, MX_ADDK); R.id1 = rdlane(xv, MX_ID1); R.big1 = rdlane(xv, MX_BIG1); R.small1 = rdlane(xv, MX_SMALL1);
+            R.id2 = rdlane(xv, MX_ID2); R.big2 = rdlane(xv, MX_BIG2); R.small2 = rdlane(xv, MX_SMALL2); R.sus = rdlane(xv, MX_SUS);
+            wave_sync();
+            mw_stage(stage, R, lane);
+            nclr = R.w_clr & ~R.bit_clr; nset = R.w_set | R.bit_set;
+            if (R.wid_clr == R.wid_set) { nclr |= R.bit_set; nset = nclr; }
         }
 
-        // ---- Bounds::check; accept or drop (src/lib.rs:185-191) -- under the token, as little as possible
-        const bool l16 = lane < 16;
+        // ---- Bounds::check; accept or drop (src/lib.rs:185-191) -- under the token, as little as possible: LDS only.
+        // The commit's global stores are issued after the token is handed on: until this wave publishes them as
+        // visible (vis, at its next proposal) every later proposal holds this decision against its reads anyway.
+        MW_T(t_redo);
+        const bool l16 = lane < 8;
         const u64 cnt = l16 ? cntL[lane] : 0ull, bmin = l16 ? bminL[lane] : 0ull, bmax = l16 ? bmaxL[lane] : ~0ull;
-        const u32 in_bounds = mw_uni(ctl[1]);
-        const u64 ncnt = cnt + (u64)myd;
+        const u32 sv = lane < ML_WORDS ? stage[lane] : (lane == 16 ? ctl[1] : 0u);   // the staged log entry; lane 16: inside the bounds?
+        const u32 in_bounds = rdlane(sv, 16);
+        const u64 ncnt = cnt + (u64)R.myd;
         const u32 within = ballot(ncnt < bmin || ncnt > bmax) == 0ull ? 1u : 0u;
-        const u32 commit = nonempty & within;
-        if (commit) {
-            if (l16) cntL[lane] = ncnt;
-            if (lane == 0) {
-                if (!in_bounds) ctl[1] = 1u;
-                if (wid_clr == wid_set) {   // both changes in one word (double-edge move only)
-                    rows[wid_clr] = (w_clr & ~bit_clr) | bit_set;
-                } else {
-                    rows[wid_clr] = w_clr & ~bit_clr;
-                    rows[wid_set] = w_set | bit_set;
-                }
-                if (is_dmove) dbl[dslot] = dnew;
-            }
+        const u32 commit = R.nonempty & within;
+        MW_T(t_dec1);
+        if (commit && l16) cntL[lane] = ncnt;
+        if (lane < ML_WORDS) logL[(q & ring) * ML_WORDS + lane] = lane == 0 ? (sv | commit) : sv;
+        if (commit && !in_bounds && lane == 0) ctl[1] = 1u;
+        MW_T(t_dec2);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the log entry and the counts
+        __hip_atomic_store(&ctl[0], q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (commit && lane == 0) {
+            C.rows[R.wid_clr] = nclr;
+            C.rows[R.wid_set] = nset;
+            if (R.is_dmove) C.dbl[R.dslot] = R.dnew;
         }
-        if (lane < ML_WORDS) {
-            u32 v = commit | (is_dmove << 1);
-            v = lane == ML_BIG1 ? big1 : v; v = lane == ML_SMALL1 ? small1 : v; v = lane == ML_ID1 ? id1 : v;
-            v = lane == ML_BIG2 ? big2 : v; v = lane == ML_SMALL2 ? small2 : v; v = lane == ML_ID2 ? id2 : v;
-            v = lane == ML_DSLOT ? dslot : v; v = lane == ML_WCLR ? wid_clr : v; v = lane == ML_WSET ? wid_set : v;
-            logL[(q & (W - 1u)) * ML_WORDS + lane] = v;
+#ifdef MW_STAMP
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const u64 t_rel = __builtin_amdgcn_s_memtime();
+            st_acc[0] += t_snap - t_start;     // table entry, vis publish (waits for this wave's earlier stores), snap
+            st_acc[1] += t_run - t_snap;       // the proposal: lists, builds, evaluations
+            st_acc[2] += t_token - t_run;      // staging, checks, waiting for the token
+            st_acc[3] += t_redo - t_token;     // exact re-run (when hit)
+            st_acc[4] += t_rel - t_redo;       // decision under the token
+            st_acc[5] += 1;
+            st_acc[6] += (t_dec1 - t_redo) | ((t_dec2 - t_dec1) << 32);   // decision split: LDS reads + check | stores
         }
-        __hip_atomic_store(&ctl[0], q + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 
         // ---- the token is gone: this wave's counters (sampled += 1, src/lib.rs:185)
-        status |= sus;
+        status |= R.sus;
         mine += 1u;
-        accepted += commit | ((nonempty ^ 1u) & in_bounds);   // an empty transition is accepted iff the state is inside the bounds
-        n_empty += nonempty ^ 1u;
-        n_dmove += nonempty & is_dmove;
-        n_flip += nonempty & (is_dmove ^ 1u);
-        sum_k += add_k;
-        n_wide += used_wide;
-        n_big += big_set;
-        if (nonempty) {
-            if (ballot(myd < 0 && cnt < (u64)(-myd))) status |= 8u;  // reference assert, src/lib.rs:65
-            const u64 nz = ballot(l16 && ncnt != 0ull);              // flag_count never shrinks in length (src/lib.rs:72-74)
+        accepted += commit | ((R.nonempty ^ 1u) & in_bounds);   // an empty transition is accepted iff the state is inside the bounds
+        n_empty += R.nonempty ^ 1u;
+        n_dmove += R.nonempty & R.is_dmove;
+        sum_k += R.add_k;
+        n_wide += R.used_wide;
+        n_big += R.big_set;
+        if (R.nonempty) {
+            if (ballot(R.myd < 0 && cnt < (u64)(-R.myd))) status |= 8u;  // reference assert, src/lib.rs:65
+            const u64 nz = ballot(l16 && ncnt != 0ull);                // flag_count never shrinks in length (src/lib.rs:72-74)
             const u32 nlen = nz ? (u32)(64 - __clzll((long long)nz)) : 0u;
             if (nlen > count_len) count_len = nlen;
         }
     }
 
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&vis[wv], MW_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // all of this wave's commits are in memory
+#ifdef MW_STAMP
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&p.dbgbuf[(size_t)chain * 8 + i], (unsigned long long)st_acc[i]);
+#endif
     mw_barrier();   // every proposal decided
     if (wv == 0 && lane < p.ncounts) ((u64 *)p.counts + (size_t)chain * FCM_DEV_MAX_COUNTS)[lane] = cntL[lane];
     if (lane == 0) {
         atomicAdd((unsigned long long *)&st_g[0], (unsigned long long)mine);
         atomicAdd((unsigned long long *)&st_g[1], (unsigned long long)accepted);
         atomicAdd((unsigned long long *)&st_g[2], (unsigned long long)n_empty);
-        atomicAdd((unsigned long long *)&st_g[3], (unsigned long long)n_flip);
+        atomicAdd((unsigned long long *)&st_g[3], (unsigned long long)(mine - n_empty - n_dmove));
         atomicAdd((unsigned long long *)&st_g[4], (unsigned long long)n_dmove);
         atomicAdd((unsigned long long *)&st_g[5], (unsigned long long)sum_k);
         atomicMax((unsigned long long *)&st_g[6], (unsigned long long)count_len);
