@@ -59,14 +59,10 @@ __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
             wave_sync();
             Hs[lane] = myH;
             wave_sync();
-            int delta[FCM_COUNT_MAXT + 1];
-#pragma unroll
-            for (int q = 0; q <= FCM_COUNT_MAXT; ++q) delta[q] = 0;
-            // every vertex of C comes after v: one class, the raw masks are the clique graph
-            if (lane < (int)total) delta[1] += 1;
-            if (myH) visit<1, FCM_COUNT_MAXT, true>(myH, Hs, FCM_COUNT_MAXT, +1, delta, overflow);
-#pragma unroll
-            for (int q = 1; q <= FCM_COUNT_MAXT; ++q) acc[q] += (u64)(u32)delta[q];
+            // every vertex of C comes after v: one class, the raw masks are the clique graph.  64-bit counts per lane:
+            // one edge of a dense graph can carry more than 2^31 simplices of the higher dimensions.
+            if (lane < (int)total) acc[1] += 1;
+            if (myH) visit<1, FCM_COUNT_MAXT, true, u64>(myH, Hs, FCM_COUNT_MAXT, +1, acc, overflow);
         } else {
             Wide V = W;
             V.NW = (int)((total + 63u) >> 6);

@@ -50,6 +50,7 @@ struct FcmStepParams {
     uint64_t *dbgbuf;          // [n_chains][8] cycle sums of a -DFCM_STAMP diagnostic build; unused otherwise
     int32_t ncounts;           // tracked count entries NC (<= 16)
     int32_t maxnw;             // mask words the largest local set needs: ceil((k_max+2)/64), 1..4
+    uint64_t guard_limit;      // largest local count bound a walk may reach before it refuses (2^31 - 1; fcm_count_guard)
     uint32_t mw_waves;         // multi-wave kernel (fcm_step_mw.hpp): waves per chain, a power of two 2..16; 0 = one-wave kernel
 };
 

@@ -915,6 +915,8 @@ try {
     p.nchains = C;
     p.ncounts = nc;
     p.maxnw = s->maxnw_variant;
+    p.guard_limit = 0x7FFFFFFFull;
+    if (const char *e = getenv("FCM_TEST_GUARD_LIMIT")) p.guard_limit = strtoull(e, nullptr, 10);   // test hook (tests/test_gpu_parity.py)
 
     if (s->cfg.sample_distance == 0) s->cfg.sample_distance = fcm_default_sample_distance(fc[1]);  // sample.rs:102
 
@@ -931,10 +933,11 @@ try {
     I.lossless = lossless ? 1 : 0;
     I.n_chains = C;
     // Simple moves run with several waves per chain (fcm_step_mw.hpp): W consecutive proposals in flight, decided in order.
-    // W is chosen so that chains x W fills the chip (8192 wave slots): 2 from 4096 chains up, 16 for 512 and fewer.
+    // W is chosen so that chains x W fills the chip (8192 wave slots): 2 from 4096 chains up, 4 from 2048, 8 below (more
+    // than 8 proposals in flight buy nothing: the in-order decisions, some hundred cycles each, are the limit by then).
     // FCM_MW=<1|2|4|8|16> overrides (1 = the one-wave kernel).
     {
-        uint32_t W = C >= 4096 ? 2u : (C >= 2048 ? 4u : (C >= 1024 ? 8u : 16u));
+        uint32_t W = C >= 4096 ? 2u : (C >= 2048 ? 4u : 8u);
         if (const char *e = getenv("FCM_MW")) {
             const int v = atoi(e);
             W = (v == 2 || v == 4 || v == 8 || v == 16) ? (uint32_t)v : 1u;

@@ -87,7 +87,8 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
 // Sum of a 32-bit value over the wave with DPP adds (no LDS): prefix sums
 // inside each row of 16 lanes (row_shr 1,2,4,8), then row_bcast:15 / :31 carry
 // the row totals upward.  The total lands in lane 63 and is returned uniform.
-// Per-proposal local simplex counts are far below 2^31.
+// Whether the per-lane counts and this sum stay below 2^31 is checked per evaluation where it is not a
+// matter of course (fcm_count_guard below).
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -381,8 +382,8 @@ __device__ __forceinline__ bool extras_fit(const Cls &c, int s)
 
 // Plain clique walk.  A node has T vertices chosen; `cand` = its children
 // (non-empty).  delta[t] accumulates sign * (#cliques with t vertices).
-template <int T, int MAXT, bool DETECT>
-__device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sign, int (&delta)[MAXT + 1], u32 &overflow)
+template <int T, int MAXT, bool DETECT, class ACC = int>
+__device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sign, ACC (&delta)[MAXT + 1], u32 &overflow)
 {
     if constexpr (T < MAXT) {
         if (T + 1 <= tmax) {
@@ -393,7 +394,7 @@ __device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sig
                     const int x = __ffsll((long long)c) - 1;
                     c &= c - 1;
                     const u64 nc = cand & Hp[x];
-                    if (nc) visit<T + 1, MAXT, DETECT>(nc, Hp, tmax, sign, delta, overflow);
+                    if (nc) visit<T + 1, MAXT, DETECT, ACC>(nc, Hp, tmax, sign, delta, overflow);
                 }
             }
         } else if (DETECT) {
@@ -402,6 +403,30 @@ __device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sig
     } else if (DETECT) {
         overflow = 1u;
     }
+}
+
+// 32-bit guard.  The walk keeps its counts in 32-bit integers per lane and sums them over the wave in 32 bits.  A
+// split graph with tp arcs and at most m children per node holds at most tp * m^(t-2) ordered cliques of t nodes, so up
+// to 5 tracked levels (tp <= 256, m <= 64: 6.7e7) nothing can wrap.  Deeper than that a dense reciprocal local set can
+// get there (13 parts of 4 vertices, all pairs reciprocal: 5e9 ordered 6-cliques through one edge), so kernels with
+// MAXT >= 6 check the bound per evaluation and raise a status bit -- the run then fails loudly at the next read-out --
+// instead of returning wrapped counts.  FcmGuard::limit = 2^31 - 1 (FcmStepParams::guard_limit; a test hook lowers it).
+struct FcmGuard { u64 limit; u32 tripped; };
+__device__ __forceinline__ void fcm_count_guard(int nch, int tp, int tmax, FcmGuard *g)
+{
+    if (!g) return;
+    int m = nch;   // wave maximum of the child counts
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));
+    const u64 mm = (u64)(u32)__builtin_amdgcn_readlane(m, 63);
+    const u64 lim = g->limit;
+    u64 b = (u64)(u32)tp;
+    for (int t = 3; t <= tmax && b <= lim; ++t) b *= mm;
+    if (b > lim) g->tripped = 1u;
 }
 
 // The walk over the split graph in Hp (lane x = node x, `row` = its children).  One lane per
@@ -413,7 +438,7 @@ __device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sig
 #define FCM_PAIR_CAP 256
 template <int MAXT>
 __device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1],
-                                           u64 *sacc = nullptr, u64 *stt = nullptr)
+                                           u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
 {
     u32 dummy = 0;
     if constexpr (MAXT >= 3) {
@@ -421,6 +446,7 @@ __device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int
             const int nch = __popcll(row);
             const int incl = wave_scan_i32(nch);
             const int tp = __builtin_amdgcn_readlane(incl, 63);
+            if constexpr (MAXT >= 6) fcm_count_guard(nch, tp, tmax, guard);
             if (tp <= FCM_PAIR_CAP) {
                 delta[2] += sign * nch;
                 if (tp == 0) return;
@@ -451,7 +477,7 @@ __device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int
 // endpoints.  Requires extras_fit(c, k+2).
 template <int MAXT>
 __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k, int tmax, int sign, int lane,
-                                           int (&delta)[MAXT + 1], u64 *sacc = nullptr, u64 *stt = nullptr)
+                                           int (&delta)[MAXT + 1], u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     const u64 uv = 3ull << k;
@@ -492,7 +518,7 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
     wave_sync();
     FCM_STAMP_PTR(3);                                                  // (flips-only diagnostic) classes, seating, split rows
     if (tmax >= 1 && cls != 3) delta[1] += sign;
-    walk_nodes<MAXT>(row, Hp, tmax, sign, lane, delta, sacc, stt);
+    walk_nodes<MAXT>(row, Hp, tmax, sign, lane, delta, sacc, stt, guard);
     wave_sync();
 }
 
@@ -507,7 +533,7 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
 __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
-                                         u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
+                                         u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1], FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     u64 myH = build_local(rows, stride32, Lv, s, lane);
@@ -521,8 +547,8 @@ __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv
     c2.P = c.P; c2.S = c.S;
     c2.M = (ab ? hk : hk1) & ballot((myH >> iv) & 1ull) & ~(3ull << k);
     if (!extras_fit(c, s) || !extras_fit(c2, s)) return FCM_NEEDS_WIDE;
-    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
-    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta);
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, nullptr, nullptr, guard);
+    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta, nullptr, nullptr, guard);
     return ab ? 1 : 2;
 }
 
@@ -531,7 +557,7 @@ __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
 __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
-                                        u32 coin, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1])
+                                        u32 coin, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1], FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     const u64 myH = build_local(rows, stride32, Lv, s, lane);
@@ -539,7 +565,7 @@ __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv,
     const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
     const Cls c = classify(myH, iv, iu);
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
-    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta);
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, nullptr, nullptr, guard);
     return (ab & ba) ? 1 : 0;
 }
 
@@ -549,7 +575,7 @@ __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv,
 // the local set Lv (k vertices of K, then big, small), built by the caller.
 template <int MAXT>
 __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u32 dfrom, u32 dto, u64 *Hp, int lane,
-                                              int tmax, int (&delta)[MAXT + 1])
+                                              int tmax, int (&delta)[MAXT + 1], FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     const bool act = lane < s;
@@ -562,7 +588,7 @@ __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u
     if (lane == ia) myH |= (1ull << ib);
     const Cls c = classify(myH, ia, ib);
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
-    eval_nodes<MAXT>(myH, Hp, c, k, tmax, +1, lane, delta);
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, +1, lane, delta, nullptr, nullptr, guard);
     return 1;
 }
 
@@ -875,6 +901,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     // transition is "accepted", src/lib.rs:186-187)
     bool in_bounds = ballot(cl && (cnt < bmin || cnt > bmax)) == 0ull;
 
+    FcmGuard guard = {p.guard_limit, 0u};
     FCM_STAMP_DECL
     for (u64 done = 0; done < p.nprop; done += WAVE) {
         // ---- batch: lane s draws proposal `sampled + s` ------------------
@@ -967,7 +994,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             FCM_STAMP_AT(3);                           // flip: two evaluations
                         }
 #else
-                        res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hp, lane, tmax, delta);
+                        res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hp, lane, tmax, delta, &guard);
 #endif
                     }
                     if (res == FCM_NEEDS_WIDE) {
@@ -1070,12 +1097,12 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         bool okd = true;
                         if (!go_wide) {
                             // (1) remove delme: subtract simplices through it
-                            const int r1 = del_eval<MAXT>(rrows, stride32, Lv1, dk, coin, Hp, lane, tmax, delta);
+                            const int r1 = del_eval<MAXT>(rrows, stride32, Lv1, dk, coin, Hp, lane, tmax, delta, &guard);
                             go_wide = r1 == FCM_NEEDS_WIDE;
                             okd = r1 != 0;
                             if (!go_wide) {
                                 // (2) add eb->ea on the graph without delme: add simplices through it
-                                const int r2 = add_eval_built<MAXT>(myH2, Lv2, rk, rfwd, dfrom, dto, Hp, lane, tmax, delta);
+                                const int r2 = add_eval_built<MAXT>(myH2, Lv2, rk, rfwd, dfrom, dto, Hp, lane, tmax, delta, &guard);
                                 go_wide = r2 == FCM_NEEDS_WIDE;
                             }
                         }
@@ -1110,7 +1137,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 #else
                     u64 *clq_sacc = nullptr, *clq_stt = nullptr;
 #endif
-                    const CliqueResult cr = clique_propose<MAXT>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta, clq_sacc, clq_stt);
+                    const CliqueResult cr = clique_propose<MAXT>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta, clq_sacc, clq_stt, &guard);
                     status |= cr.status;
                     if (cr.nchg > 0) {
                         nonempty = true;
@@ -1202,6 +1229,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         FCM_STAMP_AT(7);                                               // (batch boundary)
     }
 
+    if (guard.tripped) status |= 256u;   // a local count may have passed 2^31: refuse rather than wrap
     if (cl) cnt_g[lane] = cnt;
     if (lane == 0) {
         st_g[0] = sampled; st_g[1] = accepted; st_g[2] = n_empty; st_g[3] = n_flip;

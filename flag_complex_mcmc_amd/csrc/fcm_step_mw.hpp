@@ -40,6 +40,9 @@
 // against its reads.  All waves of a workgroup run on one CU and share its vector L1: workgroup scope.
 #pragma once
 
+#ifndef MW_MINW
+#define MW_MINW 8
+#endif
 #define MW_NONE 0xFFFFFFFFu
 // log entry, u32 words: what a decision changed (flags = 0: nothing)
 enum { ML_FLAGS = 0, ML_BIG1, ML_SMALL1, ML_ID1, ML_BIG2, ML_SMALL2, ML_ID2, ML_DSLOT, ML_WCLR, ML_WSET, ML_WORDS = 12 };
@@ -49,7 +52,7 @@ enum { ML_FLAGS = 0, ML_BIG1, ML_SMALL1, ML_ID1, ML_BIG2, ML_SMALL2, ML_ID2, ML_
 // chain context, u32 words in LDS: what the out-of-line parts (table fill, exact run) need, so that the hot loop
 // does not have to keep it in registers
 enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SEED = 10, MC_SAMPLED0 = 12, MC_CUM0 = 14, MC_CUM1 = 16,
-       MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_WORDS = 28 };
+       MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_WORDS = 28 };
 
 // result of an exact run, u32 words in the wave's LDS
 enum { MX_FLAGS = 0, MX_WCLR, MX_WSET, MX_BCLR, MX_BSET, MX_OCLR, MX_OSET, MX_DSLOT, MX_DNEW, MX_ADDK, MX_ID1, MX_BIG1, MX_SMALL1, MX_ID2,
@@ -153,7 +156,7 @@ __device__ __forceinline__ void mw_stage(u32 *stage, const MwProp &R, int lane)
 // evaluator), on a state nobody else changes meanwhile.
 template <int MAXT, bool ROWS128, bool EXACT>
 __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds, int maxnw, u32 tv, u64 tt, u32 gchain, u64 seed, int lane, MwProp &R,
-                                       u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u)
+                                       u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u, u64 guard_limit = 0x7FFFFFFFull)
 {
     const int tmax = MAXT;
     // The snap point (hot path only): between the static loads of the proposal (table entry, vertex lists) and its first
@@ -175,6 +178,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     R.id1 = R.big1 = R.small1 = R.id2 = R.big2 = R.small2 = R.cx0 = R.cx1 = MW_NONE; R.sus = 0u;
     R.Lv1 = MW_NONE; R.Lv2 = MW_NONE;
     R.myd = 0; R.snap = 0u;
+    FcmGuard guard = {guard_limit, 0u};
     const int move = (int)(rdlane(tv, 0) & 0xFFu);
     const u32 coin = (rdlane(tv, 0) >> 8) & 1u;
     const u64 idx = (u64)rdlane(tv, 2) | ((u64)rdlane(tv, 3) << 32);
@@ -379,13 +383,14 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
 #pragma nounroll
         for (int ev = 0; ev < 2; ++ev) {
             const Cls c = ev ? cB : cA;
-            eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta);
+            eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta, nullptr, nullptr, &guard);
         }
 #pragma unroll
         for (int tq = 1; tq <= MAXT; ++tq) {
             const int sum = wave_sum_i32(delta[tq]);
             if (lane == tq + 1) R.myd = (long long)sum;
         }
+        if (guard.tripped) R.sus |= 256u;   // a local count may have passed 2^31: refuse rather than wrap
     }
 }
 
@@ -405,7 +410,8 @@ __device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 t
     const u64 seed = (u64)rdlane(cv, MC_SEED) | ((u64)rdlane(cv, MC_SEED + 1) << 32);
     const u64 sampled0 = (u64)rdlane(cv, MC_SAMPLED0) | ((u64)rdlane(cv, MC_SAMPLED0 + 1) << 32);
     MwProp R;
-    mw_run<MAXT, ROWS128, true>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, R);
+    mw_run<MAXT, ROWS128, true>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, R, nullptr, 0u, 0u, 0u,
+                                (u64)rdlane(cv, MC_GUARD) | ((u64)rdlane(cv, MC_GUARD + 1) << 32));
     u32 *out = (u32 *)(mine_lds + 64);
     if (lane == 0) {
         out[MX_FLAGS] = (R.nonempty ? MXF_NONEMPTY : 0u) | (R.is_dmove ? MXF_DMOVE : 0u) | (R.used_wide ? MXF_WIDE : 0u) | (R.big_set ? MXF_BIG : 0u);
@@ -489,6 +495,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
     const u32 *T = (const u32 *)(mine_lds + 128);          // this wave's next 32 proposals
     u64 *st_g = (u64 *)p.stats + (size_t)chain * FCM_DEV_NSTATS;
 
+    const u64 guard_limit = MAXT >= 6 ? p.guard_limit : 0ull;
     MwChain C;
     C.rows = p.rows + (size_t)chain * p.rows_per_chain;
     C.dbl = p.dbl + (size_t)chain * p.dbl_stride;
@@ -512,7 +519,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             *(u64 *)(ctx + MC_SAMPLED0) = st_g[0];         // Philox step index of proposal 0 of this launch
             *(u64 *)(ctx + MC_CUM0) = p.cum0; *(u64 *)(ctx + MC_CUM1) = p.cum1; *(u64 *)(ctx + MC_CUM2) = p.cum2;
             ctx[MC_U] = C.U; ctx[MC_D] = C.D; ctx[MC_STRIDE32] = C.stride32; ctx[MC_GCHAIN] = p.first_chain + chain;
-            ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = W;
+            ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = W; *(u64 *)(ctx + MC_GUARD) = p.guard_limit;
         }
     }
     mw_barrier();
@@ -547,7 +554,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // those from snap on are held against this proposal's reads before it is decided.
         MwProp R;
         MW_T(t_snap);
-        mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, R, vis, wv, q, W);
+        mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, R, vis, wv, q, W, guard_limit);
         const u32 snap = R.snap;
         MW_T(t_run);
 
@@ -687,7 +694,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 
 // (W is a launch parameter: the block is W x 64 threads.  8 waves per SIMD whatever W is: at most 64 VGPRs.)
 template <int MAXT, bool ROWS128>
-__global__ __launch_bounds__(16 * WAVE, 8) void fcm_step_mw_kernel(const FcmStepParams p)
+__global__ __launch_bounds__(16 * WAVE, MW_MINW) void fcm_step_mw_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];
     if (blockIdx.x >= p.nchains) return;

@@ -625,8 +625,8 @@ def test_multi_wave_kernel_is_selected_and_switchable(fcm, monkeypatch):
     g = fcm.Graph.from_edges(500, e)
     fc = g.flagser_count()
     b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.05))
-    assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["waves_per_chain"] == 16        # few chains: many waves each
-    assert fcm.MCMCSampler(g, b, n_chains=1024, seed=1).info["waves_per_chain"] == 8
+    assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["waves_per_chain"] == 8         # few chains: many waves each
+    assert fcm.MCMCSampler(g, b, n_chains=2048, seed=1).info["waves_per_chain"] == 4
     assert fcm.MCMCSampler(g, b, n_chains=4096, seed=1).info["waves_per_chain"] == 2      # chains x W = the chip's 8192 wave slots
     assert fcm.MCMCSampler(g, b, n_chains=2, seed=1, move_weights=fcm.MOVE_DISTRIBUTION).info["waves_per_chain"] == 1  # clique moves
     monkeypatch.setenv("FCM_MW", "1")
@@ -740,3 +740,38 @@ def test_bench_kernel_natural_selection_oracle_twins(fcm, oracle):
     s, tw = _run_parity(fcm, oracle, n, e, n_chains=4, steps=[3000], seed=2, relaxation=0.05, first_chain_id=40)
     assert s.info["waves_per_chain"] >= 2 and 12 <= s.info["k_mean"] <= 48
     assert (s.stats()["status"] == 0).all()
+
+
+# ---- 32-bit local counts -------------------------------------------------------
+@pytest.mark.parametrize("mw", ["1", "8"])
+def test_local_count_guard_refuses_instead_of_wrapping(fcm, monkeypatch, mw):
+    """Kernels that track 6 and more levels bound every evaluation's counts (arcs x max children^(t-2)) and raise a status
+    bit when the bound passes 2^31 - 1.  No graph that small enough to count here gets there, so the test
+    lowers the limit through the library's test hook and checks that the run then fails loudly at the next read-out,
+    on both step kernels; with the real limit the same run is clean."""
+    n, e = load_flag_fixture("bug_calc_relax_de.flag")     # 8 count entries: the 6-level kernels
+    g = fcm.Graph.from_edges(n, e)
+    monkeypatch.setenv("FCM_MW", mw)
+    ok = fcm.initialize_new_sampler(g, n_chains=4, seed=1)
+    assert ok.ncounts == 8
+    ok.step(2000)
+    assert (ok.stats()["status"] == 0).all()
+    monkeypatch.setenv("FCM_TEST_GUARD_LIMIT", "40")
+    bad = fcm.initialize_new_sampler(g, n_chains=4, seed=1)
+    bad.step(2000)
+    with pytest.raises(fcm.FcmError) as ei:
+        bad.stats()
+    assert ei.value.code == 8 and "0x100" in str(ei.value)
+
+
+def test_count_kernel_counts_past_2_to_31_per_edge(fcm):
+    """Complete 7-partite graph, parts of 7, every pair reciprocal, on 49 vertices: count[d] = C(7,d+1) 7^(d+1) (d+1)!
+    -- 4.2e9 6-simplices in all and far more than 2^31 / 64 per lane of the counting wave: the per-lane accumulators
+    are 64 bits wide."""
+    import math
+    parts, size = 7, 7
+    n = parts * size
+    e = np.array([(a, b) for a in range(n) for b in range(n) if a // size != b // size], np.uint32)
+    want = [math.comb(parts, d + 1) * size ** (d + 1) * math.factorial(d + 1) for d in range(parts)]
+    assert want[6] > 2 ** 31
+    assert fcm.Graph.from_edges(n, e).flagser_count() == want
