@@ -340,6 +340,33 @@ __device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, in
     return lane < s ? (h & (s >= 64 ? ~0ull : ((1ull << s) - 1ull))) : 0ull;  // rows >= s were read in whole groups of 8
 }
 
+// The same with the two rows of the pair itself (local indices k, k+1: big, small) read FIRST, in a register of their own
+// (lanes 0..31: row big, lanes 32..63: row small).  Besides the in-mask bits k and k+1 that register holds the two
+// bitmap words a commit of this pair rewrites -- dword (small >> 5) of row big, dword (big >> 5) of row small -- so they
+// come out of the build's own round trip instead of a dependent one of their own.
+__device__ __forceinline__ u64 build_local_rows128_pair(const rsrc_t rsrc, u32 Lv, int k, int lane, u32 big, u32 small, u32 &w_bs, u32 &w_sb)
+{
+    const u32 sel = lane >= 32 ? 4u : 0u, dw = (u32)(lane & 31) * 4u, src = (Lv >> 5) * 4u, bpos = Lv & 31u;
+    const int s = k + 2;
+    const u32 wp = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ((lane >= 32 ? small : big) << 7) + dw, 0, 0);
+    u32 hlo = 0u, hhi = 0u;
+    {   // rows 0..47 of K: 24 registers in flight with the pair's, one round trip
+        u32 w[24];
+        build128_issue<0, 0, 6, 24>(rsrc, Lv, sel, dw, k, w);
+        build128_consume<0, 0, 6, 24>(w, src, bpos, k, hlo, hhi);
+    }
+    const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute((int)src, (int)wp), x1 = (u32)__builtin_amdgcn_ds_bpermute((int)(src + 128u), (int)wp);
+    w_bs = rdlane(wp, (int)(small >> 5));
+    w_sb = rdlane(wp, 32 + (int)(big >> 5));
+    if (k > 48) {   // rows 48..61 of K: a second trip, the registers are free again
+        u32 w[8];
+        build128_issue<6, 6, 8, 8>(rsrc, Lv, sel, dw, k, w);
+        build128_consume<6, 6, 8, 8>(w, src, bpos, k, hlo, hhi);
+    }
+    u64 h = ((u64)hlo | ((u64)hhi << 32)) & ((1ull << k) - 1ull);   // K rows were read in whole groups of 8 (k <= 62)
+    h |= (u64)(__builtin_amdgcn_ubfe(x0, bpos, 1u) | (__builtin_amdgcn_ubfe(x1, bpos, 1u) << 1)) << k;
+    return lane < s ? h : 0ull;
+}
 // ---------------------------------------------------------------------------
 // Counting the simplices through an edge u->v on the local set.
 //
@@ -406,11 +433,14 @@ __device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sig
 }
 
 // 32-bit guard.  The walk keeps its counts in 32-bit integers per lane and sums them over the wave in 32 bits.  A
-// split graph with tp arcs and at most m children per node holds at most tp * m^(t-2) ordered cliques of t nodes, so up
-// to 5 tracked levels (tp <= 256, m <= 64: 6.7e7) nothing can wrap.  Deeper than that a dense reciprocal local set can
-// get there (13 parts of 4 vertices, all pairs reciprocal: 5e9 ordered 6-cliques through one edge), so kernels with
-// MAXT >= 6 check the bound per evaluation and raise a status bit -- the run then fails loudly at the next read-out --
-// instead of returning wrapped counts.  FcmGuard::limit = 2^31 - 1 (FcmStepParams::guard_limit; a test hook lowers it).
+// split graph with tp arcs (<= 256, <= 4 per lane) and at most m <= 62 children per node holds at most tp * m^(t-2)
+// ordered cliques of t nodes.  Up to 5 tracked levels that is below 6.7e7: nothing can wrap.  With 6 levels a lane
+// stays below 4 * 62^4 = 5.9e7, but the wave's sum can pass 2^31 on a dense reciprocal local set (13 parts of 4
+// vertices, all pairs reciprocal: 5e9 ordered 6-cliques through one edge): those kernels (MAXT == 6) check the lanes'
+// magnitudes before summing (fcm_lane_guard: all below 2^24, so the sum is below 2^30).  Deeper kernels (MAXT >= 7,
+// the generic ones) can wrap inside a lane: they bound every walk by tp * m^(t-2), m = the wave's largest child count
+// (fcm_count_guard).  Either way a status bit is raised and the run fails loudly at the next read-out instead of
+// returning wrapped counts.  FcmGuard::limit = 2^31 - 1 (FcmStepParams::guard_limit; a test hook lowers it).
 struct FcmGuard { u64 limit; u32 tripped; };
 __device__ __forceinline__ void fcm_count_guard(int nch, int tp, int tmax, FcmGuard *g)
 {
@@ -427,6 +457,18 @@ __device__ __forceinline__ void fcm_count_guard(int nch, int tp, int tmax, FcmGu
     u64 b = (u64)(u32)tp;
     for (int t = 3; t <= tmax && b <= lim; ++t) b *= mm;
     if (b > lim) g->tripped = 1u;
+}
+
+template <int MAXT>
+__device__ __forceinline__ void fcm_lane_guard(const int (&delta)[MAXT + 1], FcmGuard &g)
+{
+    if constexpr (MAXT == 6) {
+        int m = 0;
+#pragma unroll
+        for (int t = 3; t <= MAXT; ++t) m = max(m, max(delta[t], -delta[t]));
+        const u64 lim = g.limit < (1ull << 30) ? g.limit : (1ull << 30);
+        if (ballot((u64)(u32)m * 64ull > lim)) g.tripped = 1u;
+    }
 }
 
 // The walk over the split graph in Hp (lane x = node x, `row` = its children).  One lane per
@@ -446,7 +488,7 @@ __device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int
             const int nch = __popcll(row);
             const int incl = wave_scan_i32(nch);
             const int tp = __builtin_amdgcn_readlane(incl, 63);
-            if constexpr (MAXT >= 6) fcm_count_guard(nch, tp, tmax, guard);
+            if constexpr (MAXT >= 7) fcm_count_guard(nch, tp, tmax, guard);
             if (tp <= FCM_PAIR_CAP) {
                 delta[2] += sign * nch;
                 if (tp == 0) return;
@@ -1166,6 +1208,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = W.cnt[lane - 1];
                     wave_sync();
                 } else {
+                    fcm_lane_guard<MAXT>(delta, guard);
 #pragma unroll
                     for (int tq = 1; tq <= MAXT; ++tq) {
                         if (tq <= tmax) {

@@ -195,3 +195,19 @@ def test_graph_allocation_failure_is_an_error_code(fcm):
     with pytest.raises(fcm.FcmError) as ei:
         fcm.Graph.new_disconnected(200000)
     assert ei.value.code == 4
+
+
+def test_headline_kernel_has_no_spill_traffic_in_its_loop():
+    """hipcc cross-compiles here: the multi-wave kernel the bench times (m4: rows of one cache line, 4 levels) must keep
+    its proposal loop free of scratch (VGPR spill) instructions -- at 64 VGPRs a small edit can tip the allocation, and
+    spill traffic inside the loop costs tens of per cent.  About a dozen such instructions belong to the
+    two out-of-line calls."""
+    import subprocess
+    src = os.path.join(ROOT, "flag_complex_mcmc_amd", "csrc")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
+                          "-DFCM_TAG=m4_0", "-DFCM_MAXT=4", "-DFCM_EXACT=1", "-DFCM_PC=1", "-DFCM_CLIQUE=0", "-S", "--cuda-device-only",
+                          "-o", "-", "fcm_step_variant.hip"], cwd=src, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    body = out.stdout[out.stdout.index("_Z18fcm_step_mw_kernel"):]
+    body = body[:body.index("s_endpgm")]
+    assert body.count("scratch_") <= 16, body.count("scratch_")

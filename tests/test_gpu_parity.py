@@ -745,8 +745,8 @@ def test_bench_kernel_natural_selection_oracle_twins(fcm, oracle):
 # ---- 32-bit local counts -------------------------------------------------------
 @pytest.mark.parametrize("mw", ["1", "8"])
 def test_local_count_guard_refuses_instead_of_wrapping(fcm, monkeypatch, mw):
-    """Kernels that track 6 and more levels bound every evaluation's counts (arcs x max children^(t-2)) and raise a status
-    bit when the bound passes 2^31 - 1.  No graph that small enough to count here gets there, so the test
+    """Kernels that track 6 levels check the lanes' counts before the 32-bit wave sum, deeper ones bound every walk (arcs x
+    max children^(t-2)); past 2^31 - 1 they raise a status bit.  No graph that small enough to count here gets there, so the test
     lowers the limit through the library's test hook and checks that the run then fails loudly at the next read-out,
     on both step kernels; with the real limit the same run is clean."""
     n, e = load_flag_fixture("bug_calc_relax_de.flag")     # 8 count entries: the 6-level kernels
