@@ -140,7 +140,7 @@ struct MwProp {
     u32 id1, big1, small1, id2, big2, small2, cx0, cx1, sus, snap;
     u32 Lv1, Lv2;       // per lane: the local vertex lists the run read
                         // (w_clr, w_set: the bitmap words the commit rewrites, as the builds read them)
-    long long myd;      // per lane: lane d holds the change of count[d]
+    int myd;            // per lane: lane d holds the change of count[d] (32 bits: fcm_lane_guard / the wide evaluator's own check)
 };
 
 // the log entry of a proposal, all but its ACCEPTED bit, into the wave's staging words (lane 0 writes: scalars)
@@ -167,7 +167,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     // Where the commit's two bitmap words come from: out of the build's own round trip (PAIRW), or read at the end of the
     // run.  The first saves a dependent round trip; it is used where hipcc fits it into 64 VGPRs without scratch traffic
     // in the loop (tools/scratch_census.sh counts it per variant).
-    constexpr bool PAIRW = ROWS128 && (MAXT == 4 || MAXT == 5);
+    constexpr bool PAIRW = false;   // (measured: no gain at 4096 chains, and at 64 VGPRs it tips hipcc's allocation into scratch traffic on small edits)
     // The snap point (hot path only): between the static loads of the proposal (table entry, vertex lists) and its first
     // load of mutable state.  The wave's earlier commit stores have completed by then (s_waitcnt vmcnt(0), which the
     // vertex list needs anyway): publish that, and note from where on decisions have to be held against this proposal.
@@ -240,7 +240,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                         const Wide Wd = wide_carve(wide_lds, maxnw);
                         wide_zero_counts(Wd, lane);
                         const int res = wide_flip(Wd, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
-                        if (lane >= 2 && lane < 16 && lane - 1 <= tmax) R.myd = Wd.cnt[lane - 1];
+                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                         if constexpr (PAIRW) { f_wbs = mw_uni(C.rows[wid_bs]); f_wsb = mw_uni(C.rows[wid_sb]); }
                         wave_sync();
                         R.used_wide = 1u;
@@ -372,7 +372,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     wide_zero_counts(Wd, lane);
                     okd = wide_del(Wd, C.rows, stride32, C.nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
                     wide_add(Wd, C.rows, stride32, C.nb, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax);
-                    if (lane >= 2 && lane < 16 && lane - 1 <= tmax) R.myd = Wd.cnt[lane - 1];
+                    { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                     wave_sync();
                     R.used_wide = 1u;
                 }
@@ -412,7 +412,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
 #pragma unroll
         for (int tq = 1; tq <= MAXT; ++tq) {
             const int sum = wave_sum_i32(delta[tq]);
-            if (lane == tq + 1) R.myd = (long long)sum;
+            if (lane == tq + 1) R.myd = sum;
         }
         if (guard.tripped) R.sus |= 256u;   // a local count may have passed 2^31: refuse rather than wrap
     }
@@ -444,7 +444,7 @@ __device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 t
         out[MX_ID1] = R.id1; out[MX_BIG1] = R.big1; out[MX_SMALL1] = R.small1;
         out[MX_ID2] = R.id2; out[MX_BIG2] = R.big2; out[MX_SMALL2] = R.small2; out[MX_SUS] = R.sus;
     }
-    if (lane < 16) ((long long *)(out + MX_WORDS))[lane] = R.myd;
+    if (lane < 16) ((int *)(out + MX_WORDS))[lane] = R.myd;
     wave_sync();
 }
 
@@ -576,6 +576,8 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 
         // ---- the proposal on the state as committed now.  Commits below snap are visible to every load from here on;
         // those from snap on are held against this proposal's reads before it is decided.
+        // the oldest undecided proposal is what the chain's other waves end up waiting for: let it go first on its SIMD
+        if (mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == q) __builtin_amdgcn_s_setprio(2);
         MwProp R;
         MW_T(t_snap);
         mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, R, vis, wv, q, W, guard_limit);
@@ -620,6 +622,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             else __builtin_amdgcn_s_sleep(1);
         }
         MW_T(t_token);
+        __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
         if (hit) {
             // under the token nobody else can commit; once every earlier commit is in memory too, run it again, all of it
             n_redo += 1u;
@@ -627,7 +630,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             mw_exact_call<MAXT, ROWS128>(smem, wv, tv, q);
             const u32 *out = (const u32 *)(mine_lds + 64);
             const u32 xv = lane < MX_WORDS ? out[lane] : 0u;
-            if (lane < 16) R.myd = ((const long long *)(out + MX_WORDS))[lane];
+            if (lane < 16) R.myd = ((const int *)(out + MX_WORDS))[lane];
             const u32 fl = rdlane(xv, MX_FLAGS);
             R.nonempty = fl & 1u; R.is_dmove = (fl >> 1) & 1u; R.used_wide = (fl >> 2) & 1u; R.big_set = (fl >> 3) & 1u;
             R.wid_clr = rdlane(xv, MX_WCLR); R.wid_set = rdlane(xv, MX_WSET); R.bit_clr = rdlane(xv, MX_BCLR); R.bit_set = rdlane(xv, MX_BSET);
@@ -648,7 +651,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         const u64 cnt = l16 ? cntL[lane] : 0ull, bmin = l16 ? bminL[lane] : 0ull, bmax = l16 ? bmaxL[lane] : ~0ull;
         const u32 sv = lane < ML_WORDS ? stage[lane] : (lane == 16 ? ctl[1] : 0u);   // the staged log entry; lane 16: inside the bounds?
         const u32 in_bounds = rdlane(sv, 16);
-        const u64 ncnt = cnt + (u64)R.myd;
+        const u64 ncnt = cnt + (u64)(long long)R.myd;
         const u32 within = ballot(ncnt < bmin || ncnt > bmax) == 0ull ? 1u : 0u;
         const u32 commit = R.nonempty & within;
         MW_T(t_dec1);
@@ -658,6 +661,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         MW_T(t_dec2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the log entry and the counts
         __hip_atomic_store(&ctl[0], q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_s_setprio(0);
         if (commit && lane == 0) {
             C.rows[R.wid_clr] = nclr;
             C.rows[R.wid_set] = nset;
@@ -687,7 +691,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         n_wide += R.used_wide;
         n_big += R.big_set;
         if (R.nonempty) {
-            if (ballot(R.myd < 0 && cnt < (u64)(-R.myd))) status |= 8u;  // reference assert, src/lib.rs:65
+            if (ballot(R.myd < 0 && cnt < (u64)(-(long long)R.myd))) status |= 8u;  // reference assert, src/lib.rs:65
             const u64 nz = ballot(l16 && ncnt != 0ull);                // flag_count never shrinks in length (src/lib.rs:72-74)
             const u32 nlen = nz ? (u32)(64 - __clzll((long long)nz)) : 0u;
             if (nlen > count_len) count_len = nlen;
