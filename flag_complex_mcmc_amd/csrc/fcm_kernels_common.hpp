@@ -340,33 +340,6 @@ __device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, in
     return lane < s ? (h & (s >= 64 ? ~0ull : ((1ull << s) - 1ull))) : 0ull;  // rows >= s were read in whole groups of 8
 }
 
-// The same with the two rows of the pair itself (local indices k, k+1: big, small) read FIRST, in a register of their own
-// (lanes 0..31: row big, lanes 32..63: row small).  Besides the in-mask bits k and k+1 that register holds the two
-// bitmap words a commit of this pair rewrites -- dword (small >> 5) of row big, dword (big >> 5) of row small -- so they
-// come out of the build's own round trip instead of a dependent one of their own.
-__device__ __forceinline__ u64 build_local_rows128_pair(const rsrc_t rsrc, u32 Lv, int k, int lane, u32 big, u32 small, u32 &w_bs, u32 &w_sb)
-{
-    const u32 sel = lane >= 32 ? 4u : 0u, dw = (u32)(lane & 31) * 4u, src = (Lv >> 5) * 4u, bpos = Lv & 31u;
-    const int s = k + 2;
-    const u32 wp = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ((lane >= 32 ? small : big) << 7) + dw, 0, 0);
-    u32 hlo = 0u, hhi = 0u;
-    {   // rows 0..47 of K: 24 registers in flight with the pair's, one round trip
-        u32 w[24];
-        build128_issue<0, 0, 6, 24>(rsrc, Lv, sel, dw, k, w);
-        build128_consume<0, 0, 6, 24>(w, src, bpos, k, hlo, hhi);
-    }
-    const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute((int)src, (int)wp), x1 = (u32)__builtin_amdgcn_ds_bpermute((int)(src + 128u), (int)wp);
-    w_bs = rdlane(wp, (int)(small >> 5));
-    w_sb = rdlane(wp, 32 + (int)(big >> 5));
-    if (k > 48) {   // rows 48..61 of K: a second trip, the registers are free again
-        u32 w[8];
-        build128_issue<6, 6, 8, 8>(rsrc, Lv, sel, dw, k, w);
-        build128_consume<6, 6, 8, 8>(w, src, bpos, k, hlo, hhi);
-    }
-    u64 h = ((u64)hlo | ((u64)hhi << 32)) & ((1ull << k) - 1ull);   // K rows were read in whole groups of 8 (k <= 62)
-    h |= (u64)(__builtin_amdgcn_ubfe(x0, bpos, 1u) | (__builtin_amdgcn_ubfe(x1, bpos, 1u) << 1)) << k;
-    return lane < s ? h : 0ull;
-}
 // ---------------------------------------------------------------------------
 // Counting the simplices through an edge u->v on the local set.
 //

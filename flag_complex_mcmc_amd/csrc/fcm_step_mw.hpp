@@ -85,15 +85,11 @@ __device__ __forceinline__ void mw_barrier()   // orders LDS only
 __device__ __forceinline__ u32 mw_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 mw_uni64(u64 v) { return (u64)mw_uni((u32)v) | ((u64)mw_uni((u32)(v >> 32)) << 32); }
 
-// in-masks of the local set Lv (k vertices of K, then big, small).  Rows of one cache line: the build also hands out the
-// two bitmap words of the pair (big->small's, small->big's), which its own round trip has fetched; longer rows: mw_run
-// reads them at its end.
-template <bool ROWS128, bool PAIRW>
-__device__ __forceinline__ u64 mw_build(const rsrc_t rr, u32 stride32, u32 Lv, int k, int lane, u32 big, u32 small, u32 &w_bs, u32 &w_sb)
+template <bool ROWS128>
+__device__ __forceinline__ u64 mw_build(const rsrc_t rr, u32 stride32, u32 Lv, int s, int lane)
 {
-    if constexpr (PAIRW) return build_local_rows128_pair(rr, Lv, k, lane, big, small, w_bs, w_sb);
-    else if constexpr (ROWS128) return build_local_rows128(rr, Lv, k + 2, lane);
-    else return build_local_loop16(rr, stride32, Lv, k + 2, lane);
+    if constexpr (ROWS128) return build_local_rows128(rr, Lv, s, lane);
+    else return build_local_loop16(rr, stride32, Lv, s, lane);
 }
 
 // both endpoints of the pair (big, small) in the local list Lv?  (lanes beyond the list repeat its last vertex)
@@ -164,10 +160,6 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                                        u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u, u64 guard_limit = 0x7FFFFFFFull)
 {
     const int tmax = MAXT;
-    // Where the commit's two bitmap words come from: out of the build's own round trip (PAIRW), or read at the end of the
-    // run.  The first saves a dependent round trip; it is used where hipcc fits it into 64 VGPRs without scratch traffic
-    // in the loop (tools/scratch_census.sh counts it per variant).
-    constexpr bool PAIRW = false;   // (measured: no gain at 4096 chains, and at 64 VGPRs it tips hipcc's allocation into scratch traffic on small edits)
     // The snap point (hot path only): between the static loads of the proposal (table entry, vertex lists) and its first
     // load of mutable state.  The wave's earlier commit stores have completed by then (s_waitcnt vmcnt(0), which the
     // vertex list needs anyway): publish that, and note from where on decisions have to be held against this proposal.
@@ -208,13 +200,12 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             const FcmEdgeEntry e1 = {rdlane(tv, 4), rdlane(tv, 5), rdlane(tv, 6), rdlane(tv, 7)};
             const int k = (int)e1.k;
             int fres = 0;          // 1 = big->small is flipped, 2 = small->big
-            u32 f_wbs = 0u, f_wsb = 0u;   // the pair's two bitmap words as the build saw them
             R.id1 = (u32)idx; R.big1 = e1.big; R.small1 = e1.small;
             const u32 wid_bs = e1.big * stride32 + (e1.small >> 5), wid_sb = e1.small * stride32 + (e1.big >> 5);   // the words of big->small, small->big
             if (k + 2 <= WAVE) {
                 R.Lv1 = load_list(C.nb, e1.nb_off, k, e1.big, e1.small, lane);
                 snap_point();
-                const u64 myH = mw_build<ROWS128, PAIRW>(rr, stride32, R.Lv1, k, lane, e1.big, e1.small, f_wbs, f_wsb);
+                const u64 myH = mw_build<ROWS128>(rr, stride32, R.Lv1, k + 2, lane);
                 const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
                 const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);  // big->small, small->big
                 if (ab == ba) {
@@ -241,7 +232,6 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                         wide_zero_counts(Wd, lane);
                         const int res = wide_flip(Wd, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
                         { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
-                        if constexpr (PAIRW) { f_wbs = mw_uni(C.rows[wid_bs]); f_wsb = mw_uni(C.rows[wid_sb]); }
                         wave_sync();
                         R.used_wide = 1u;
                         if (res < 0) R.sus |= 1u;
@@ -256,7 +246,6 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                 const u32 cf = fres == 1 ? e1.big : e1.small, ct = fres == 1 ? e1.small : e1.big;
                 R.wid_clr = fres == 1 ? wid_bs : wid_sb; R.bit_clr = 1u << (ct & 31u);
                 R.wid_set = fres == 1 ? wid_sb : wid_bs; R.bit_set = 1u << (cf & 31u);
-                if constexpr (PAIRW) { R.w_clr = fres == 1 ? f_wbs : f_wsb; R.w_set = fres == 1 ? f_wsb : f_wbs; }
                 R.add_k = (u32)k; R.big_set = k + 2 > 48 ? 1u : 0u;
             }
         }
@@ -284,7 +273,6 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
         u64 cand = 0ull, cand_next = 0ull;
         bool found = false;
         u32 rfwd = 0u;
-        u32 c_wbs = 0u, c_wsb = 0u, p_wbs = 0u, p_wsb = 0u;   // the two bitmap words of the candidate pair / of the slot's pair, as the builds saw them
 #pragma nounroll
         for (int ci = 0; ci < (EXACT ? WAVE : 3) && !found && !R.need_exact; ++ci) {
             if (ci < 2) {
@@ -315,7 +303,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     } else {
                         R.Lv2 = load_list(C.nb, e2.nb_off, ck, e2.big, e2.small, lane);
                     }
-                    HB = mw_build<ROWS128, PAIRW>(rr, stride32, R.Lv2, ck, lane, e2.big, e2.small, c_wbs, c_wsb);
+                    HB = mw_build<ROWS128>(rr, stride32, R.Lv2, ck + 2, lane);
                     f = (u32)(rdlane64(HB, ck + 1) >> ck) & 1u;
                     bwd = (u32)(rdlane64(HB, ck) >> (ck + 1)) & 1u;
                 } else {
@@ -324,7 +312,6 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                         break;
                     } else {  // wide candidate: look at its two words directly
                         const u32 wf = mw_uni(C.rows[e2.big * stride32 + (e2.small >> 5)]), wb = mw_uni(C.rows[e2.small * stride32 + (e2.big >> 5)]);
-                        if constexpr (PAIRW) { c_wbs = wf; c_wsb = wb; }
                         f = (wf >> (e2.small & 31u)) & 1u;
                         bwd = (wb >> (e2.big & 31u)) & 1u;
                         R.Lv2 = MW_NONE;
@@ -344,7 +331,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             bool okd = true;
             if (!go_wide) {
                 R.Lv1 = load_list(C.nb, e1.nb_off, dk, e1.big, e1.small, lane);
-                HA = mw_build<ROWS128, PAIRW>(rr, stride32, R.Lv1, dk, lane, e1.big, e1.small, p_wbs, p_wsb);
+                HA = mw_build<ROWS128>(rr, stride32, R.Lv1, dk + 2, lane);
                 // (1) remove the direction the coin picks from the reciprocal pair
                 const u32 ab = (u32)((rdlane64(HA, dk + 1) >> dk) & 1ull), ba = (u32)((rdlane64(HA, dk) >> (dk + 1)) & 1ull);
                 okd = (ab & ba) != 0u;
@@ -381,23 +368,16 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             R.nonempty = 1u; R.is_dmove = 1u;
             R.wid_clr = dfrom * stride32 + (dto >> 5); R.bit_clr = 1u << (dto & 31u);
             R.wid_set = eb * stride32 + (ea >> 5); R.bit_set = 1u << (ea & 31u);
-            // delme = big->small of the slot's pair if coin; the new edge is small->big of the candidate pair if its single edge is big->small
-            if constexpr (PAIRW) {
-                R.w_clr = coin ? p_wbs : p_wsb; R.w_set = rfwd ? c_wsb : c_wbs;
-                if (go_wide) { R.w_clr = mw_uni(C.rows[R.wid_clr]); R.w_set = mw_uni(C.rows[R.wid_set]); }   // (the wide run builds its own sets)
-            }
             R.dnew = (u32)cand;
             R.add_k = (u32)(dk + rk); R.big_set = (dk + 2 > 48 || rk + 2 > 48) ? 1u : 0u;
         }
     }
     snap_point();   // (paths without a load of mutable state)
-    if constexpr (!PAIRW) {
-        // the two words a commit rewrites, read here -- lines the builds have just touched.
-        // Issued last, so that the round trip runs beside the wait for the token instead of in front of it.
-        if (R.nonempty) {
-            R.w_clr = C.rows[R.wid_clr];
-            R.w_set = C.rows[R.wid_set];
-        }
+    // the two bitmap words a commit rewrites, read here -- lines the builds have just touched -- so that the commit is
+    // two plain stores.  Issued last: the round trip runs beside the wait for the token instead of in front of it.
+    if (R.nonempty) {
+        R.w_clr = C.rows[R.wid_clr];
+        R.w_set = C.rows[R.wid_set];
     }
     if (nev) {
         int delta[MAXT + 1];

@@ -195,9 +195,10 @@ int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 #define FCM_STAT_CPERM 8      /* non-empty clique_permute proposals */
 #define FCM_STAT_CSWAP 9      /* non-empty clique_swap proposals */
 #define FCM_STAT_CHANGES 10   /* directed edges changed by clique-move proposals */
-#define FCM_STAT_REDO 11      /* two-wave kernel: proposals the consumer handed back (REDO) for an exact run by the producer */
+#define FCM_STAT_REDO 11      /* multi-wave kernel: proposals run again under the token (a commit in flight touched what they had read, or they
+                                 need the full candidate search / the wide evaluator); a timing diagnostic, not chain state */
 #define FCM_STAT_WIDE 12      /* proposals evaluated by the wide (multi-word, LDS) evaluator */
-#define FCM_STAT_BIG 13       /* evaluated local sets of more than 48 vertices (second build trip of the two-wave kernel) */
+#define FCM_STAT_BIG 13       /* evaluated local sets of more than 48 vertices (second trip of the whole-row build) */
 int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out);
 
 /* Directed edge list of one chain's current graph, ascending (from,to). */
