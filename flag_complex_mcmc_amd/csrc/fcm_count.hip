@@ -51,7 +51,13 @@ __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
             total += tot;
         }
         if (total == 0) continue;
-        if (total > WAVE * FCM_COUNT_MAXNW) { toolarge = 1u; continue; }
+        if (total > WAVE * FCM_COUNT_MAXNW) {   // more than 256 common out-neighbours: left to the second pass (fcm_count_xw_kernel)
+            if (lane == 0) {
+                const u32 at = atomicAdd(&p.xlist[0], 1u);
+                if (at < p.xcap) p.xlist[1 + at] = (u32)e;
+            }
+            continue;
+        }
         wave_sync();
         if (total <= WAVE) {
             const u32 Lv = lane < (int)total ? Lc[lane] : 0u;
@@ -90,6 +96,48 @@ __global__ __launch_bounds__(WAVE) void fcm_count_kernel(const FcmCountParams p)
     }
     if (ballot(toolarge != 0u) && lane == 0) atomicOr(&p.flags[0], 1u);
     if (ballot(overflow != 0u) && lane == 0) atomicOr(&p.flags[1], 1u);
+}
+
+// Second pass: the directed edges whose endpoints have 257 .. 1024 common out-neighbours, one wave each, masks in a
+// workspace in global memory (fcm_xwide.hpp).
+__global__ __launch_bounds__(WAVE) void fcm_count_xw_kernel(const FcmCountParams p, u32 nflagged)
+{
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= nflagged) return;
+    const u64 e = p.xlist[1 + blockIdx.x];
+    u64 *ws = (u64 *)p.xw_ws + (size_t)blockIdx.x * FCM_XW_WORDS;
+    const u32 nwords = (p.n + 31u) >> 5;
+    const u32 u = p.edges[2 * e], v = p.edges[2 * e + 1];
+    const u32 *ru = p.rows + (size_t)u * p.stride32, *rv = p.rows + (size_t)v * p.stride32;
+    XWide X = xw_carve(ws, 64);
+    u32 total = 0;
+    for (u32 w0 = 0; w0 < nwords; w0 += WAVE) {   // compact out(u) & out(v) into the list
+        const u32 w = w0 + lane;
+        u32 x = (w < nwords) ? (ru[w] & rv[w]) : 0u;
+        const u32 c = __popc(x);
+        const u32 inc = (u32)wave_scan_i32((int)c);
+        u32 pos = total + inc - c;
+        while (x) {
+            const u32 b = __ffs((int)x) - 1;
+            x &= x - 1;
+            if (pos < 64u * FCM_XW_MAXNW) X.L[pos] = w * 32u + b;
+            ++pos;
+        }
+        total += rdlane(inc, WAVE - 1);
+    }
+    if (total > 64u * FCM_XW_MAXNW) { if (lane == 0) atomicOr(&p.flags[0], 1u); return; }
+    if (lane < 16) X.cnt[lane] = 0;
+    xw_sync();
+    X.NW = (int)((total + 63u) >> 6);
+    xw_build(X, p.rows, p.stride32, (int)total, lane);
+    XCls c;   // every vertex comes after v: one class
+    c.P = 0ull; c.M = 0ull;
+    const int rem = (int)total - 64 * lane;
+    c.S = lane < X.NW ? (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) : 0ull;
+    u32 overflow = 0u;
+    xw_dfs(X, c, FCM_COUNT_MAXT, +1, lane, &overflow);
+    if (lane >= 1 && lane <= FCM_COUNT_MAXT && X.cnt[lane]) atomicAdd((unsigned long long *)&p.counts[lane + 1], (unsigned long long)X.cnt[lane]);
+    if (overflow && lane == 0) atomicOr(&p.flags[1], 1u);
 }
 
 // rows[c] = base for every chain c; 16 B per lane, coalesced.
@@ -145,6 +193,13 @@ extern "C" int fcm_launch_count(const FcmCountParams *p, void *stream)
     const u64 maxgrid = 256ull * 32ull;
     dim3 grid((unsigned)(p->m < maxgrid ? p->m : maxgrid)), block(WAVE);
     hipLaunchKernelGGL(fcm_count_kernel, grid, block, sizeof(u64) * fcm_lds_words(FCM_COUNT_MAXNW), st, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fcm_launch_count_xw(const FcmCountParams *p, uint32_t nflagged, void *stream)
+{
+    if (nflagged == 0) return 0;
+    hipLaunchKernelGGL(fcm_count_xw_kernel, dim3(nflagged), dim3(WAVE), 0, (hipStream_t)stream, *p, nflagged);
     return (int)hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ struct FcmStepParams {
     uint64_t *dbgbuf;          // [n_chains][8] cycle sums of a -DFCM_STAMP diagnostic build; unused otherwise
     int32_t ncounts;           // tracked count entries NC (<= 16)
     int32_t maxnw;             // mask words the largest local set needs: ceil((k_max+2)/64), 1..4
+    uint64_t *xw_ws;           // [n_chains][FCM_XW_WORDS] workspace of the evaluator for local sets of 257..1024 vertices (fcm_xwide.hpp); null if the graph has none
     uint64_t guard_limit;      // largest local count bound a walk may reach before it refuses (2^31 - 1; fcm_count_guard)
     uint32_t mw_waves;         // multi-wave kernel (fcm_step_mw.hpp): waves per chain, a power of two 2..16; 0 = one-wave kernel
 };
@@ -59,8 +60,11 @@ struct FcmCountParams {
     const uint32_t *edges;     // [m][2] directed edges (from,to)
     uint64_t m;
     uint64_t *counts;          // [16], entries 2.. accumulated with atomics
-    uint32_t *flags;           // [0] != 0: local set > 64; [1] != 0: dimension > 15 present
+    uint32_t *flags;           // [0] != 0: local set too large; [1] != 0: dimension > 15 present
     uint32_t n, stride32;
+    uint32_t *xlist;           // [0] = number of edges with more than 256 common out-neighbours, [1 ..] their indices (second pass)
+    uint32_t xcap;             // entries xlist can hold
+    uint64_t *xw_ws;           // second pass: [grid][FCM_XW_WORDS] workspaces (fcm_xwide.hpp)
 };
 
 #ifdef __cplusplus
@@ -69,6 +73,7 @@ extern "C" {
 // launchers implemented in fcm_kernels.hip; `stream` is a hipStream_t
 int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, void *stream);
 int fcm_launch_count(const FcmCountParams *p, void *stream);
+int fcm_launch_count_xw(const FcmCountParams *p, uint32_t nflagged, void *stream);   // the edges of xlist, one wave each
 int fcm_launch_broadcast_rows(uint32_t *rows, const uint32_t *base, uint64_t words_per_chain, uint32_t nchains, void *stream);
 #ifdef __cplusplus
 }

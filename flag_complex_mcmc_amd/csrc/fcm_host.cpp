@@ -27,6 +27,8 @@
 
 static_assert(FCM_MAX_COUNTS == FCM_DEV_MAX_COUNTS, "count vector width");
 static_assert(FCM_NSTATS == FCM_DEV_NSTATS, "stats width");
+// u64 words of the per-chain workspace of fcm_xwide.hpp (FCM_XW_WORDS there): H[1024][16] | stack | counts | list
+static const size_t FCM_XW_WORDS_HOST = 1024u * 16u + (16u * 2u * 16u + 16u) + 16u + 512u;
 
 // ---------------------------------------------------------------------------
 // errors
@@ -267,12 +269,15 @@ static int device_count(const uint32_t *rows, uint32_t n, uint32_t stride32, con
     counts[0] = n;
     counts[1] = m;
     if (m > 0) {
-        DevBuf d_rows, d_edges, d_counts, d_flags;
+        DevBuf d_rows, d_edges, d_counts, d_flags, d_xlist, d_xw;
+        const uint32_t xcap = 4096;   // edges with more than 256 common out-neighbours a graph may have (second pass, 141 KB of workspace each)
         const size_t row_bytes = (size_t)n * stride32 * sizeof(uint32_t);
         if ((rc = d_rows.alloc(row_bytes))) return rc;
         if ((rc = d_edges.alloc(edges.size() * sizeof(uint32_t)))) return rc;
         if ((rc = d_counts.alloc(sizeof(uint64_t) * FCM_MAX_COUNTS))) return rc;
         if ((rc = d_flags.alloc(sizeof(uint32_t) * 2))) return rc;
+        if ((rc = d_xlist.alloc(sizeof(uint32_t) * (1 + xcap)))) return rc;
+        HIP_TRY(hipMemset(d_xlist.p, 0, sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(d_rows.p, rows, row_bytes, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_edges.p, edges.data(), edges.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(d_counts.p, 0, sizeof(uint64_t) * FCM_MAX_COUNTS));
@@ -285,9 +290,23 @@ static int device_count(const uint32_t *rows, uint32_t n, uint32_t stride32, con
         p.flags = d_flags.as<uint32_t>();
         p.n = n;
         p.stride32 = stride32;
+        p.xlist = d_xlist.as<uint32_t>();
+        p.xcap = xcap;
+        p.xw_ws = nullptr;
         int lrc = fcm_launch_count(&p, nullptr);
         if (lrc) return fail(FCM_ERR_HIP, "count kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
         HIP_TRY(hipDeviceSynchronize());
+        uint32_t nflagged = 0;
+        HIP_TRY(hipMemcpy(&nflagged, d_xlist.p, sizeof nflagged, hipMemcpyDeviceToHost));
+        if (nflagged > xcap)
+            return fail(FCM_ERR_UNSUPPORTED, "%u directed edges have more than %d common out-neighbours; this build takes at most %u such edges", nflagged, FCM_MAX_COUNT_LOCAL, xcap);
+        if (nflagged) {   // second pass: 257 .. 1024 common out-neighbours, masks in a workspace
+            if ((rc = d_xw.alloc((size_t)nflagged * FCM_XW_WORDS_HOST * sizeof(uint64_t)))) return rc;
+            p.xw_ws = d_xw.as<uint64_t>();
+            lrc = fcm_launch_count_xw(&p, nflagged, nullptr);
+            if (lrc) return fail(FCM_ERR_HIP, "count kernel (second pass) launch failed: %s", hipGetErrorString((hipError_t)lrc));
+            HIP_TRY(hipDeviceSynchronize());
+        }
         uint64_t dc[FCM_MAX_COUNTS];
         uint32_t flags[2];
         HIP_TRY(hipMemcpy(dc, d_counts.p, sizeof dc, hipMemcpyDeviceToHost));
@@ -670,7 +689,7 @@ struct fcm_sampler {
     uint32_t n = 0, stride32 = 0;
     std::vector<uint32_t> ue;          // [U][2] big, small
     // device buffers
-    DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats, d_clq, d_clq_pairs, d_efirst, d_slot_of, d_dbg;
+    DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats, d_clq, d_clq_pairs, d_efirst, d_slot_of, d_dbg, d_xw;
     bool clique_moves = false;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -753,9 +772,14 @@ try {
     }
     if (kmax + 2 > FCM_MAX_LOCAL)
         return fail(FCM_ERR_UNSUPPORTED, "an edge has %u common neighbours; this build supports at most %d", kmax, FCM_MAX_LOCAL - 2);
+    const bool clique_wanted = cfg->move_weights[2] > 0.0 || cfg->move_weights[3] > 0.0;
+    if (kmax + 2 > 256 && clique_wanted)
+        return fail(FCM_ERR_UNSUPPORTED, "an edge has %u common neighbours; the clique moves support at most 254 (simple moves: %d)", kmax, FCM_MAX_LOCAL - 2);
     // at least two mask words of LDS: the one-word path falls back to the wide one when the
-    // per-class copies of multi-class vertices do not fit in 64 nodes
+    // per-class copies of multi-class vertices do not fit in 64 nodes.  Local sets beyond 256 vertices take the
+    // evaluator with its masks in a per-chain workspace (fcm_xwide.hpp), allocated only then.
     s->maxnw_variant = kmax + 2 <= 128 ? 2 : 4;
+    const bool need_xw = kmax + 2 > 256;
     const uint64_t D = dbl0.size();
 
     // --- initial counts and the reachable dimension range ------------------
@@ -867,6 +891,7 @@ try {
         for (uint32_t c = 0; c < C && U; ++c)
             HIP_TRY(hipMemcpy(s->d_slot_of.as<uint32_t>() + (size_t)c * U, so.data(), (size_t)U * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    if (need_xw && (rc = s->d_xw.alloc((size_t)C * FCM_XW_WORDS_HOST * sizeof(uint64_t)))) return rc;
     if ((rc = s->d_dbg.alloc((size_t)C * 8 * sizeof(uint64_t)))) return rc;
     HIP_TRY(hipMemset(s->d_dbg.p, 0, (size_t)C * 8 * sizeof(uint64_t)));
     HIP_TRY(hipStreamCreate(&s->own_stream));
@@ -915,6 +940,7 @@ try {
     p.nchains = C;
     p.ncounts = nc;
     p.maxnw = s->maxnw_variant;
+    p.xw_ws = need_xw ? s->d_xw.as<uint64_t>() : nullptr;
     p.guard_limit = 0x7FFFFFFFull;
     if (const char *e = getenv("FCM_TEST_GUARD_LIMIT")) p.guard_limit = strtoull(e, nullptr, 10);   // test hook (tests/test_gpu_parity.py)
 
@@ -927,7 +953,7 @@ try {
     I.n_double = D;
     I.k_max = kmax;
     I.k_mean = U ? (double)ksum / (double)U : 0.0;
-    I.bytes_per_chain = rows_per_chain * 4 + (uint64_t)dbl_stride * 4 + FCM_MAX_COUNTS * 8 + FCM_NSTATS * 8 + (s->clique_moves ? U * 4 : 0);
+    I.bytes_per_chain = rows_per_chain * 4 + (uint64_t)dbl_stride * 4 + FCM_MAX_COUNTS * 8 + FCM_NSTATS * 8 + (s->clique_moves ? U * 4 : 0) + (need_xw ? FCM_XW_WORDS_HOST * 8 : 0);
     I.bytes_static = etab.size() * sizeof(FcmEdgeEntry) + nb.size() * 4 + ct.flat.size() * 4 + clq_pairs_bytes;
     I.ncounts = nc;
     I.lossless = lossless ? 1 : 0;

@@ -866,6 +866,7 @@ __device__ __forceinline__ void wide_add(const Wide W, const u32 *rows, u32 stri
     wide_dfs<false>(W, tmax, +1, nullptr);
 }
 
+#include "fcm_xwide.hpp"
 #include "fcm_clique.hpp"
 
 // ===========================================================================
@@ -911,6 +912,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     const u32 gchain = p.first_chain + chain;
     const u32 stride32 = p.stride32;
     const int maxnw = p.maxnw;
+    u64 *xw_ws = p.xw_ws ? (u64 *)p.xw_ws + (size_t)chain * FCM_XW_WORDS : nullptr;
 
     // is the current state inside the bounds?  (decides whether an empty
     // transition is "accepted", src/lib.rs:186-187)
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 #pragma unroll
             for (int q = 0; q <= MAXT; ++q) delta[q] = 0;
 
-            bool nonempty = false, used_wide = false;
+            bool nonempty = false, used_wide = false, used_xw = false;
             // pending commit (uniform)
             u32 c_clr_from = 0, c_clr_to = 0, c_set_from = 0, c_set_to = 0;
             // the two bitmap words a commit rewrites, read while the build is in flight so that the
@@ -1018,6 +1020,9 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             wide_zero_counts(W, lane);
                             res = wide_flip(W, rows, stride32, nb, off, k, a, b, lane, tmax);
                             used_wide = true;
+                        } else if (xw_ws && k + 2 <= 64 * FCM_XW_MAXNW) {   // 257..1024 local vertices: masks in the chain's workspace
+                            res = xw_flip(xw_ws, rows, stride32, nb, off, k, a, b, lane, tmax);
+                            used_wide = true; used_xw = true;
                         } else {
                             res = -1;
                         }
@@ -1125,7 +1130,13 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 #pragma unroll
                             for (int q = 0; q <= MAXT; ++q) delta[q] = 0;
                             if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
-                                status |= 1u;
+                                if (xw_ws && dk + 2 <= 64 * FCM_XW_MAXNW && rk + 2 <= 64 * FCM_XW_MAXNW) {
+                                    okd = xw_del(xw_ws, rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, lane, tmax);
+                                    xw_add(xw_ws, rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, lane, tmax, true);
+                                    used_wide = true; used_xw = true;
+                                } else {
+                                    status |= 1u;
+                                }
                             } else {
                                 const Wide W = wide_carve(smem, maxnw);
                                 wide_zero_counts(W, lane);
@@ -1175,7 +1186,11 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             } else {
                 if (move == 2) n_cperm += 1; else if (move == 3) n_cswap += 1; else if (is_dmove) n_dmove += 1; else n_flip += 1;
                 long long myd = 0;
-                if (used_wide) {
+                if (used_xw) {
+                    n_wide += 1;
+                    if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = xw_count(xw_ws, lane - 1);
+                    wave_sync();
+                } else if (used_wide) {
                     n_wide += 1;
                     const Wide W = wide_carve(smem, maxnw);
                     if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = W.cnt[lane - 1];

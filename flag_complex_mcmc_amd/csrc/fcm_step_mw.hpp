@@ -52,7 +52,7 @@ enum { ML_FLAGS = 0, ML_BIG1, ML_SMALL1, ML_ID1, ML_BIG2, ML_SMALL2, ML_ID2, ML_
 // chain context, u32 words in LDS: what the out-of-line parts (table fill, exact run) need, so that the hot loop
 // does not have to keep it in registers
 enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SEED = 10, MC_SAMPLED0 = 12, MC_CUM0 = 14, MC_CUM1 = 16,
-       MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_WORDS = 28 };
+       MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_XW = 28, MC_WORDS = 30 };
 
 // result of an exact run, u32 words in the wave's LDS
 enum { MX_FLAGS = 0, MX_WCLR, MX_WSET, MX_BCLR, MX_BSET, MX_OCLR, MX_OSET, MX_DSLOT, MX_DNEW, MX_ADDK, MX_ID1, MX_BIG1, MX_SMALL1, MX_ID2,
@@ -63,12 +63,12 @@ enum { MX_FLAGS = 0, MX_WCLR, MX_WSET, MX_BCLR, MX_BSET, MX_OCLR, MX_OSET, MX_DS
 #define MXF_BIG 8u
 
 // LDS map in u64 words:
-//   shared    cnt[8] | bmin[8] | bmax[8] | ctl[2] | ctx[14] | vis[8] | log[2W][6]     (<= 8 count entries: tmax <= 6)
+//   shared    cnt[8] | bmin[8] | bmax[8] | ctl[2] | ctx[15] | vis[8] | log[2W][6]     (<= 8 count entries: tmax <= 6)
 //   per wave  Hp[64] | arc list[64] | draw table: 32 entries of 14 u32 [224]   (the arc list doubles as the exact run's result)
 //   wide evaluator (one: only the token holder runs it)
-#define MW_SHARED_WORDS 48u
+#define MW_SHARED_WORDS 49u
 #define MW_CTX_OFF 26u
-#define MW_VIS_OFF 40u
+#define MW_VIS_OFF 41u
 #define MW_TBL_WORDS 14u
 #define MW_WAVE_WORDS (128u + 16u * MW_TBL_WORDS)
 __host__ __device__ inline unsigned fcm_mw_lds_words(int NW, int W)
@@ -114,6 +114,7 @@ struct MwChain {
     const u32 *nb;
     const FcmEdgeEntry *etab;
     u64 rows_bytes;
+    u64 *xw;            // workspace of the evaluator for 257..1024 local vertices, or null
     u32 U, D, stride32;
 };
 __device__ __forceinline__ MwChain mw_chain_from_lds(const u32 *ctx, int lane)
@@ -125,6 +126,7 @@ __device__ __forceinline__ MwChain mw_chain_from_lds(const u32 *ctx, int lane)
     C.nb = (const u32 *)((u64)rdlane(cv, MC_NB) | ((u64)rdlane(cv, MC_NB + 1) << 32));
     C.etab = (const FcmEdgeEntry *)((u64)rdlane(cv, MC_ETAB) | ((u64)rdlane(cv, MC_ETAB + 1) << 32));
     C.rows_bytes = (u64)rdlane(cv, MC_ROWS_BYTES) | ((u64)rdlane(cv, MC_ROWS_BYTES + 1) << 32);
+    C.xw = (u64 *)((u64)rdlane(cv, MC_XW) | ((u64)rdlane(cv, MC_XW + 1) << 32));
     C.U = rdlane(cv, MC_U); C.D = rdlane(cv, MC_D); C.stride32 = rdlane(cv, MC_STRIDE32);
     return C;
 }
@@ -227,7 +229,14 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     R.need_exact = 1u;
                 } else {
                     fres = 0;
-                    if (k + 2 <= 64 * maxnw) {
+                    if (k + 2 > 64 * maxnw && C.xw && k + 2 <= 64 * FCM_XW_MAXNW) {   // 257..1024 local vertices
+                        const int res = xw_flip(C.xw, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
+                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? xw_count(C.xw, lane - 1) : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
+                        wave_sync();
+                        R.used_wide = 1u;
+                        if (res < 0) R.sus |= 1u;
+                        fres = res > 0 ? res : 0;
+                    } else if (k + 2 <= 64 * maxnw) {
                         const Wide Wd = wide_carve(wide_lds, maxnw);
                         wide_zero_counts(Wd, lane);
                         const int res = wide_flip(Wd, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
@@ -353,7 +362,15 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                 if constexpr (!EXACT) {
                     R.need_exact = 1u;
                 } else if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
-                    R.sus |= 1u;
+                    if (C.xw && dk + 2 <= 64 * FCM_XW_MAXNW && rk + 2 <= 64 * FCM_XW_MAXNW) {
+                        okd = xw_del(C.xw, C.rows, stride32, C.nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
+                        xw_add(C.xw, C.rows, stride32, C.nb, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax, true);
+                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? xw_count(C.xw, lane - 1) : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
+                        wave_sync();
+                        R.used_wide = 1u;
+                    } else {
+                        R.sus |= 1u;
+                    }
                 } else {
                     const Wide Wd = wide_carve(wide_lds, maxnw);
                     wide_zero_counts(Wd, lane);
@@ -505,6 +522,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
     C.dbl = p.dbl + (size_t)chain * p.dbl_stride;
     C.nb = p.nb; C.etab = p.etab;
     C.rows_bytes = p.rows_per_chain * 4ull;
+    C.xw = p.xw_ws ? (u64 *)p.xw_ws + (size_t)chain * FCM_XW_WORDS : nullptr;
     C.U = p.U; C.D = p.D; C.stride32 = p.stride32;
 
     if (wv == 0) {
@@ -523,7 +541,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             *(u64 *)(ctx + MC_SAMPLED0) = st_g[0];         // Philox step index of proposal 0 of this launch
             *(u64 *)(ctx + MC_CUM0) = p.cum0; *(u64 *)(ctx + MC_CUM1) = p.cum1; *(u64 *)(ctx + MC_CUM2) = p.cum2;
             ctx[MC_U] = C.U; ctx[MC_D] = C.D; ctx[MC_STRIDE32] = C.stride32; ctx[MC_GCHAIN] = p.first_chain + chain;
-            ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = W; *(u64 *)(ctx + MC_GUARD) = p.guard_limit;
+            ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = W; *(u64 *)(ctx + MC_GUARD) = p.guard_limit; *(u64 *)(ctx + MC_XW) = (u64)C.xw;
         }
     }
     mw_barrier();

@@ -46,10 +46,13 @@ extern "C" {
  * undirected clique number exceeds 16 are refused unless a dim_cap is given. */
 #define FCM_MAX_COUNTS 16
 
-/* Largest local vertex set (|N(a) cap N(b)| + 2 for a move, |out(u) cap out(v)|
- * for the counter) the kernels support: one 64-lane wave holds up to four
- * local vertices per lane. */
-#define FCM_MAX_LOCAL 256
+/* Largest local vertex set a move may have (|N(a) cap N(b)| + 2).  Up to 64 vertices: the fast evaluator (one mask word
+ * per lane); up to 256: the wide one (masks in LDS); up to 1024: masks in a per-chain workspace in HBM, allocated only for
+ * graphs that have such a pair (simple moves; with clique moves on the limit is 256).  The counter (flagser_count) takes the
+ * same 1024 common out-neighbours of a directed edge (beyond 256 in a second pass, for at most 4096 such edges).  The
+ * reference has no such limits; beyond them: FCM_ERR_UNSUPPORTED. */
+#define FCM_MAX_LOCAL 1024
+#define FCM_MAX_COUNT_LOCAL 256   /* first pass of the counter */
 
 typedef uint32_t fcm_node;     /* reference `Node` = u32 (src/flagser.rs:5,9) */
 

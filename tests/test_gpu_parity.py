@@ -242,11 +242,16 @@ def test_unsupported_inputs_fail_loudly(fcm):
     with pytest.raises(fcm.FcmError) as ei:
         fcm.MCMCSampler(big, fcm.Bounds([20], [20]))
     assert ei.value.code == 4
-    # a common neighbourhood beyond 254 vertices (4 mask words per lane)
-    t = 300
+    # a common neighbourhood beyond 1022 vertices (simple moves), beyond 254 with clique moves on
+    t = 1100
     book = [(0, 1)] + [(0, w) for w in range(2, t)] + [(1, w) for w in range(2, t)]
     with pytest.raises(fcm.FcmError) as ei:
         fcm.MCMCSampler(fcm.Graph.from_edges(t, book), fcm.Bounds([t], [t]))
+    assert ei.value.code == 4
+    t = 300
+    book = [(0, 1)] + [(0, w) for w in range(2, t)] + [(1, w) for w in range(2, t)]
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MCMCSampler(fcm.Graph.from_edges(t, book), fcm.Bounds([t], [t]), move_weights=fcm.MOVE_DISTRIBUTION)
     assert ei.value.code == 4
 
 
@@ -287,14 +292,35 @@ def test_wide_neighbourhoods(fcm, oracle, t, p_page):
     assert (st["n_flip"] > 0).all() and (st["n_dmove"] > 0).all()
 
 
-def test_count_wide_common_out_neighbourhood(fcm, oracle):
-    # 0->1, 0->w, 1->w for 200 pages: out(0) & out(1) has 200 vertices
-    t = 202
+@pytest.mark.parametrize("t,p_page,mw", [(300, 0.008, "1"), (600, 0.004, "1"), (600, 0.004, "8"), (1000, 0.0015, "2")])
+def test_local_sets_beyond_256_vertices(fcm, oracle, monkeypatch, t, p_page, mw):
+    """the reference recounts whatever neighbourhood a pair has (src/lib.rs:62-71).  The pair {0,1} of
+    this graph has every other vertex as a common neighbour: local sets of 300, 600 and 1000 vertices, which take the
+    evaluator with its masks in the chain's HBM workspace (fcm_xwide.hpp), in the one-wave kernel and under the token of
+    the multi-wave kernel.  Oracle twins, tolerance 0; the hub pair is proposed a few times per chain."""
+    monkeypatch.setenv("FCM_MW", mw)
+    e = _book_graph(t, p_page, seed=t)
+    go = oracle.Graph.from_edges(t, e)
+    s, tw = _run_parity(fcm, oracle, t, e, n_chains=3, steps=[64, 3000], seed=t + 1, relaxation=0.3)
+    assert s.info["k_max"] == t - 2 and s.info["waves_per_chain"] == int(mw)
+    st = s.stats()
+    assert (st["status"] == 0).all() and st["n_wide"].sum() > 0, "the hub pair was never evaluated"
+
+
+@pytest.mark.parametrize("t", [202, 258, 602, 1026])
+def test_count_wide_common_out_neighbourhood(fcm, oracle, t):
+    # 0->1, 0->w, 1->w for t-2 pages: out(0) & out(1) has t-2 vertices (beyond 256: the counter's second pass)
     e = [(0, 1)] + [(0, w) for w in range(2, t)] + [(1, w) for w in range(2, t)]
     rng = np.random.default_rng(0)
-    e += [(int(i), int(j)) for i in range(2, t) for j in range(2, t) if i != j and rng.random() < 0.02]
+    e += [(int(i), int(j)) for i in range(2, t) for j in range(2, t) if i != j and rng.random() < 4.0 / t]
     e = np.array(e, np.uint32)
     assert fcm.Graph.from_edges(t, e).flagser_count() == oracle.Graph.from_edges(t, e).flagser_count()
+    # one more page than the counter takes: refused, not truncated
+    if t == 1026:
+        e2 = np.concatenate([e, np.array([(0, t), (1, t)], np.uint32)])
+        with pytest.raises(fcm.FcmError) as ei:
+            fcm.Graph.from_edges(t + 1, e2).flagser_count()
+        assert ei.value.code == 4
 
 
 # -------------------------------------------------- edgebits (src/io.rs) -----
