@@ -99,7 +99,7 @@ struct CliqueResult {
 template <int MAXT>
 __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, const rsrc_t rrows, u64 *smem, const CliqueLds CL, int move,
                                                        u32 w1, u64 x64, u64 step, u32 gchain, u32 k0, u32 k1, int lane, int tmax,
-                                                       int maxnw, int (&delta)[MAXT + 1], u64 *sacc, u64 *stt, FcmGuard *guard = nullptr)
+                                                       int maxnw, int (&delta)[MAXT + 1], EvScal &es, u64 *sacc, u64 *stt, FcmGuard *guard = nullptr)
 {
     CliqueResult res = {0, 0, 0ull, 0ll, 0u};
     u64 *Hp = smem + WAVE;
@@ -291,8 +291,8 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
             cbs.M = inS & outB & nbm;
             csb.M = inB & outS & nbm;
             if ((!need_bs || extras_fit(cbs, s)) && (!need_sb || extras_fit(csb, s))) {
-                if (need_bs) eval_nodes<MAXT>(myH, Hp, cbs, k, tmax, n_bs ? +1 : -1, lane, delta, nullptr, nullptr, guard);
-                if (need_sb) eval_nodes<MAXT>(myH, Hp, csb, k, tmax, n_sb ? +1 : -1, lane, delta, nullptr, nullptr, guard);
+                if (need_bs) eval_nodes<MAXT>(myH, Hp, cbs, k, tmax, n_bs ? +1 : -1, lane, delta, es, nullptr, nullptr, guard);
+                if (need_sb) eval_nodes<MAXT>(myH, Hp, csb, k, tmax, n_sb ? +1 : -1, lane, delta, es, nullptr, nullptr, guard);
                 if (lane == 0) {
                     if (need_bs) *wbs = n_bs ? (vbs | bit_s) : (vbs & ~bit_s);
                     if (need_sb) *wsb = n_sb ? (vsb | bit_b) : (vsb & ~bit_b);

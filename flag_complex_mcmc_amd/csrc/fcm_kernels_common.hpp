@@ -363,10 +363,19 @@ struct Cls { u64 P, M, S; };
 
 // classes relative to u->v (local indices iu, iv) in the graph whose out-masks are myH (one per lane).
 // With the in-masks build_local makes, pass (index of v, index of u) for an edge u->v of G.
+// ballot of bit i (wave-uniform) of a 64-bit per-lane mask: one v_and on the half that holds it and one v_cmp
+__device__ __forceinline__ u64 ballot_bit(u64 h, int i)
+{
+    const u32 m = 1u << (i & 31);
+    return i < 32 ? ballot(((u32)h & m) != 0u) : ballot(((u32)(h >> 32) & m) != 0u);
+}
+// per-lane bool from a wave-uniform mask: the SGPR pair is used as the select mask directly, no VALU
+__device__ __forceinline__ bool lane_in(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 __device__ __forceinline__ Cls classify(u64 myH, int iu, int iv)
 {
     const u64 outU = rdlane64(myH, iu), outV = rdlane64(myH, iv);  // v_readlane with an SGPR lane index: no LDS round trip
-    const u64 inU = ballot((myH >> iu) & 1ull), inV = ballot((myH >> iv) & 1ull);
+    const u64 inU = ballot_bit(myH, iu), inV = ballot_bit(myH, iv);
     const u64 nbm = ~((1ull << iu) | (1ull << iv));
     Cls c;
     c.P = inU & inV & nbm;    // w->u, w->v : before u
@@ -444,7 +453,11 @@ __device__ __forceinline__ void fcm_lane_guard(const int (&delta)[MAXT + 1], Fcm
     }
 }
 
-// The walk over the split graph in Hp (lane x = node x, `row` = its children).  One lane per
+// Levels 1 and 2 of an evaluation are wave-uniform numbers -- the nodes and the arcs of the split graph -- and are kept
+// as scalars; only the deeper levels (t >= 3) are counted per lane and summed over the wave by the caller.
+struct EvScal { int d1, d2; };
+
+// The walk over the split graph in Hp (lane x = node x, `row` = its children, as two 32-bit halves).  One lane per
 // node would leave the lanes in lockstep through nested child loops whose trip counts are the
 // maxima over the wave: a handful of children per node, most lanes idle.  Instead the arcs
 // (node, child) -- about as many as there are lanes -- are listed in LDS and dealt out one per
@@ -452,88 +465,108 @@ __device__ __forceinline__ void fcm_lane_guard(const int (&delta)[MAXT + 1], Fcm
 // The list sits behind Hp (FCM_PAIR_CAP 16-bit entries).
 #define FCM_PAIR_CAP 256
 template <int MAXT>
-__device__ __forceinline__ void walk_nodes(u64 row, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1],
+__device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1], EvScal &es,
                                            u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
 {
     u32 dummy = 0;
-    if constexpr (MAXT >= 3) {
-        if (tmax >= 3) {
-            const int nch = __popcll(row);
-            const int incl = wave_scan_i32(nch);
-            const int tp = __builtin_amdgcn_readlane(incl, 63);
-            if constexpr (MAXT >= 7) fcm_count_guard(nch, tp, tmax, guard);
-            if (tp <= FCM_PAIR_CAP) {
-                delta[2] += sign * nch;
-                if (tp == 0) return;
-                unsigned short *list = (unsigned short *)(Hp + WAVE);
-                int pos = incl - nch;
-                for (u64 c = row; c; c &= c - 1) list[pos++] = (unsigned short)((u32)lane | ((u32)(__ffsll((long long)c) - 1) << 8));
-                wave_sync();
-                FCM_STAMP_PTR(4);                                      // (flips-only diagnostic) arc scan + scatter
-                for (int base = 0; base < tp; base += WAVE) {
-                    const int pi = base + lane;
-                    u64 nc = 0ull;
-                    if (pi < tp) {
-                        const u32 e = list[pi];
-                        nc = Hp[e & 0xFFu] & Hp[e >> 8];
-                    }
-                    if (nc) visit<2, MAXT, false>(nc, Hp, tmax, sign, delta, dummy);
+    if (tmax < 2) return;
+    const int nch = __popc(rlo) + __popc(rhi);
+    if constexpr (MAXT < 3) {
+        es.d2 += sign * wave_sum_i32(nch);
+        return;
+    } else {
+        const int incl = wave_scan_i32(nch);
+        const int tp = __builtin_amdgcn_readlane(incl, 63);
+        es.d2 += sign * tp;
+        if (tmax < 3 || tp == 0) return;
+        if constexpr (MAXT >= 7) fcm_count_guard(nch, tp, tmax, guard);
+        if (tp <= FCM_PAIR_CAP) {
+            // scatter the arcs: 32-bit halves (one v_ffbl per arc instead of a 64-bit find-first-set)
+            unsigned short *list = (unsigned short *)(Hp + WAVE) + (incl - nch);
+            for (u32 c = rlo; c; c &= c - 1u) *list++ = (unsigned short)((u32)lane | ((u32)(__ffs((int)c) - 1) << 8));
+            for (u32 c = rhi; c; c &= c - 1u) *list++ = (unsigned short)((u32)lane | ((u32)(__ffs((int)c) + 31) << 8));
+            wave_sync();
+            FCM_STAMP_PTR(4);                                      // (flips-only diagnostic) arc scan + scatter
+            const unsigned short *rd = (const unsigned short *)(Hp + WAVE);
+            for (int base = 0; base < tp; base += WAVE) {
+                const int pi = base + lane;
+                u64 nc = 0ull;
+                if (pi < tp) {
+                    const u32 e = rd[pi];
+                    nc = Hp[e & 0xFFu] & Hp[e >> 8];
                 }
-                FCM_STAMP_PTR(5);                                      // (flips-only diagnostic) arcs and deeper levels
-                return;
+                if (nc) visit<2, MAXT, false>(nc, Hp, tmax, sign, delta, dummy);
+            }
+            FCM_STAMP_PTR(5);                                      // (flips-only diagnostic) arcs and deeper levels
+        } else {
+            // (more arcs than the list holds: one lane per node, children in a loop)
+            const u64 row = (u64)rlo | ((u64)rhi << 32);
+            for (u64 c = row; c; c &= c - 1) {
+                const u64 nc = row & Hp[__ffsll((long long)c) - 1];
+                if (nc) visit<2, MAXT, false>(nc, Hp, tmax, sign, delta, dummy);
             }
         }
     }
-    if (row) visit<1, MAXT, false>(row, Hp, tmax, sign, delta, dummy);
+}
+
+// row bit `pos` := mask bit `orig` (both wave-uniform: the half words involved are picked by scalar branches; the empty
+// asm statements keep hipcc from turning them into selects over both halves)
+__device__ __forceinline__ void seat_bit(u32 blo, u32 bhi, u32 &rlo, u32 &rhi, int orig, int pos)
+{
+    u32 t;
+    if (orig < 32) { t = __builtin_amdgcn_ubfe(blo, (u32)orig, 1u); asm volatile("" : "+v"(t)); }
+    else { t = __builtin_amdgcn_ubfe(bhi, (u32)(orig - 32), 1u); asm volatile("" : "+v"(t)); }
+    if (pos < 32) { rlo |= t << pos; asm volatile("" : "+v"(rlo)); }
+    else { rhi |= t << (pos - 32); asm volatile("" : "+v"(rhi)); }
 }
 
 // E(G, u->v): builds the split graph for classes `c` into Hp and counts.
 // myH holds the raw local adjacency; local indices k, k+1 are the edge's
-// endpoints.  Requires extras_fit(c, k+2).
+// endpoints.  Requires extras_fit(c, k+2).  Levels 1 and 2 go to `es`, deeper ones to `delta` (per lane).
 template <int MAXT>
 __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k, int tmax, int sign, int lane,
-                                           int (&delta)[MAXT + 1], u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
+                                           int (&delta)[MAXT + 1], EvScal &es, u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     const u64 uv = 3ull << k;
     const u64 prim1 = c.M & ~c.P, prim2 = c.S & ~(c.P | c.M);
     const u64 xm = c.P & c.M, xs = c.S & (c.P | c.M);  // vertices that also need an M node / an S node
     u64 N1 = prim1, N2 = prim2;
-    u64 base = myH & ~uv;  // raw out-mask of the vertex this lane's node stands for
-    int cls = ((c.P >> lane) & 1ull) ? 0 : (((prim1 >> lane) & 1ull) ? 1 : (((prim2 >> lane) & 1ull) ? 2 : 3));
-    // pass 1: seat the extra nodes (wave-uniform loops, a handful of trips)
+    // raw out-mask of the vertex this lane's node stands for, as two halves
+    u32 blo = (u32)myH & ~(u32)uv, bhi = (u32)(myH >> 32) & ~(u32)(uv >> 32);
+    // pass 1: seat the extra nodes (wave-uniform loops, a handful of trips): the seat's lane takes the vertex's mask
     int r = 0;
     for (u64 m = xm; m; m &= m - 1, ++r) {
         const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
-        const u64 ho = rdlane64(myH, orig) & ~uv;
-        if (lane == pos) { base = ho; cls = 1; }
-        N1 |= 1ull << pos;
+        const u64 ho = rdlane64(myH, orig) & ~uv, pm = 1ull << pos;
+        const bool here = lane_in(pm);
+        blo = here ? (u32)ho : blo; bhi = here ? (u32)(ho >> 32) : bhi;
+        N1 |= pm;
     }
     for (u64 m = xs; m; m &= m - 1, ++r) {
         const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
-        const u64 ho = rdlane64(myH, orig) & ~uv;
-        if (lane == pos) { base = ho; cls = 2; }
-        N2 |= 1ull << pos;
+        const u64 ho = rdlane64(myH, orig) & ~uv, pm = 1ull << pos;
+        const bool here = lane_in(pm);
+        blo = here ? (u32)ho : blo; bhi = here ? (u32)(ho >> 32) : bhi;
+        N2 |= pm;
     }
-    // pass 2: a child vertex shows up at its own index and at each of its extras
-    u64 row = base & (c.P | prim1 | prim2);
+    // pass 2: a child vertex shows up at its own index and at each of its extras (bit `orig` of the mask goes to bit `pos`;
+    // both wave-uniform, so the half words involved are picked by scalar branches)
+    const u64 gprim = c.P | prim1 | prim2;
+    u32 rlo = blo & (u32)gprim, rhi = bhi & (u32)(gprim >> 32);
     r = 0;
-    for (u64 m = xm; m; m &= m - 1, ++r) {
-        const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
-        row |= ((base >> orig) & 1ull) << pos;
-    }
-    for (u64 m = xs; m; m &= m - 1, ++r) {
-        const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
-        row |= ((base >> orig) & 1ull) << pos;
-    }
+    for (u64 m = xm; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, r < 2 ? k + r : s + r - 2);
+    for (u64 m = xs; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, r < 2 ? k + r : s + r - 2);
     // children must not come earlier in the P*M*S* order
     const u64 G2 = N2, G1 = N1 | N2, G0 = c.P | G1;
-    row &= cls == 0 ? G0 : (cls == 1 ? G1 : (cls == 2 ? G2 : 0ull));
-    Hp[lane] = row;
+    const bool inP = lane_in(c.P), in1 = lane_in(N1), in2 = lane_in(N2);
+    rlo &= inP ? (u32)G0 : (in1 ? (u32)G1 : (in2 ? (u32)G2 : 0u));
+    rhi &= inP ? (u32)(G0 >> 32) : (in1 ? (u32)(G1 >> 32) : (in2 ? (u32)(G2 >> 32) : 0u));
+    Hp[lane] = (u64)rlo | ((u64)rhi << 32);
     wave_sync();
     FCM_STAMP_PTR(3);                                                  // (flips-only diagnostic) classes, seating, split rows
-    if (tmax >= 1 && cls != 3) delta[1] += sign;
-    walk_nodes<MAXT>(row, Hp, tmax, sign, lane, delta, sacc, stt, guard);
+    if (tmax >= 1) es.d1 += sign * __popcll(G0);
+    walk_nodes<MAXT>(rlo, rhi, Hp, tmax, sign, lane, delta, es, sacc, stt, guard);
     wave_sync();
 }
 
@@ -548,7 +581,7 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
 __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
-                                         u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1], FcmGuard *guard = nullptr)
+                                         u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     u64 myH = build_local(rows, stride32, Lv, s, lane);
@@ -562,8 +595,8 @@ __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv
     c2.P = c.P; c2.S = c.S;
     c2.M = (ab ? hk : hk1) & ballot((myH >> iv) & 1ull) & ~(3ull << k);
     if (!extras_fit(c, s) || !extras_fit(c2, s)) return FCM_NEEDS_WIDE;
-    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, nullptr, nullptr, guard);
-    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta, nullptr, nullptr, guard);
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, es, nullptr, nullptr, guard);
+    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta, es, nullptr, nullptr, guard);
     return ab ? 1 : 2;
 }
 
@@ -572,7 +605,7 @@ __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
 __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
-                                        u32 coin, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1], FcmGuard *guard = nullptr)
+                                        u32 coin, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     const u64 myH = build_local(rows, stride32, Lv, s, lane);
@@ -580,7 +613,7 @@ __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv,
     const int iu = coin ? k : k + 1, iv = coin ? k + 1 : k;
     const Cls c = classify(myH, iv, iu);
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
-    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, nullptr, nullptr, guard);
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, es, nullptr, nullptr, guard);
     return (ab & ba) ? 1 : 0;
 }
 
@@ -590,7 +623,7 @@ __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv,
 // the local set Lv (k vertices of K, then big, small), built by the caller.
 template <int MAXT>
 __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u32 dfrom, u32 dto, u64 *Hp, int lane,
-                                              int tmax, int (&delta)[MAXT + 1], FcmGuard *guard = nullptr)
+                                              int tmax, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     const bool act = lane < s;
@@ -603,7 +636,7 @@ __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u
     if (lane == ia) myH |= (1ull << ib);
     const Cls c = classify(myH, ia, ib);
     if (!extras_fit(c, s)) return FCM_NEEDS_WIDE;
-    eval_nodes<MAXT>(myH, Hp, c, k, tmax, +1, lane, delta, nullptr, nullptr, guard);
+    eval_nodes<MAXT>(myH, Hp, c, k, tmax, +1, lane, delta, es, nullptr, nullptr, guard);
     return 1;
 }
 
@@ -961,6 +994,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             int delta[MAXT + 1];
 #pragma unroll
             for (int q = 0; q <= MAXT; ++q) delta[q] = 0;
+            EvScal es = {0, 0};
 
             bool nonempty = false, used_wide = false, used_xw = false;
             // pending commit (uniform)
@@ -1003,15 +1037,15 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                                 c2.M = (ab ? hk : hk1) & ballot((myH >> iv) & 1ull) & ~(3ull << k);
                                 if (!extras_fit(c, k + 2) || !extras_fit(c2, k + 2)) res = FCM_NEEDS_WIDE;
                                 else {
-                                    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, stamp_acc, &stamp_t);
-                                    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta, stamp_acc, &stamp_t);
+                                    eval_nodes<MAXT>(myH, Hp, c, k, tmax, -1, lane, delta, es, stamp_acc, &stamp_t);
+                                    eval_nodes<MAXT>(myH, Hp, c2, k, tmax, +1, lane, delta, es, stamp_acc, &stamp_t);
                                     res = ab ? 1 : 2;
                                 }
                             }
                             FCM_STAMP_AT(3);                           // flip: two evaluations
                         }
 #else
-                        res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hp, lane, tmax, delta, &guard);
+                        res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hp, lane, tmax, delta, es, &guard);
 #endif
                     }
                     if (res == FCM_NEEDS_WIDE) {
@@ -1117,18 +1151,19 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         bool okd = true;
                         if (!go_wide) {
                             // (1) remove delme: subtract simplices through it
-                            const int r1 = del_eval<MAXT>(rrows, stride32, Lv1, dk, coin, Hp, lane, tmax, delta, &guard);
+                            const int r1 = del_eval<MAXT>(rrows, stride32, Lv1, dk, coin, Hp, lane, tmax, delta, es, &guard);
                             go_wide = r1 == FCM_NEEDS_WIDE;
                             okd = r1 != 0;
                             if (!go_wide) {
                                 // (2) add eb->ea on the graph without delme: add simplices through it
-                                const int r2 = add_eval_built<MAXT>(myH2, Lv2, rk, rfwd, dfrom, dto, Hp, lane, tmax, delta, &guard);
+                                const int r2 = add_eval_built<MAXT>(myH2, Lv2, rk, rfwd, dfrom, dto, Hp, lane, tmax, delta, es, &guard);
                                 go_wide = r2 == FCM_NEEDS_WIDE;
                             }
                         }
                         if (go_wide) {
 #pragma unroll
                             for (int q = 0; q <= MAXT; ++q) delta[q] = 0;
+                            es.d1 = es.d2 = 0;
                             if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
                                 if (xw_ws && dk + 2 <= 64 * FCM_XW_MAXNW && rk + 2 <= 64 * FCM_XW_MAXNW) {
                                     okd = xw_del(xw_ws, rows, stride32, nb, de.nb_off, dk, de.big, de.small, coin, lane, tmax);
@@ -1163,7 +1198,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 #else
                     u64 *clq_sacc = nullptr, *clq_stt = nullptr;
 #endif
-                    const CliqueResult cr = clique_propose<MAXT>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta, clq_sacc, clq_stt, &guard);
+                    const CliqueResult cr = clique_propose<MAXT>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta, es, clq_sacc, clq_stt, &guard);
                     status |= cr.status;
                     if (cr.nchg > 0) {
                         nonempty = true;
@@ -1197,8 +1232,10 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     wave_sync();
                 } else {
                     fcm_lane_guard<MAXT>(delta, guard);
+                    if (lane == 2) myd = (long long)es.d1;   // levels 1 and 2: the evaluations' node and arc counts (scalars)
+                    if (lane == 3 && tmax >= 2) myd = (long long)es.d2;
 #pragma unroll
-                    for (int tq = 1; tq <= MAXT; ++tq) {
+                    for (int tq = 3; tq <= MAXT; ++tq) {
                         if (tq <= tmax) {
                             const int sum = wave_sum_i32(delta[tq]);
                             if (lane == tq + 1) myd = (long long)sum;

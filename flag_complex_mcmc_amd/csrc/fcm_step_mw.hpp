@@ -43,6 +43,20 @@
 #ifndef MW_MINW
 #define MW_MINW 8
 #endif
+// Code-shape knobs.  They change nothing in what the kernel computes; they decide whether hipcc finds a clean
+// allocation at 64 VGPRs / 80 SGPRs for a given variant (tools/scratch_census.sh; the Makefile sets them per variant
+// from tools/tune_knobs.sh).  ZERO: the count registers are zeroed by instructions of their own.  LANE: the lane id
+// is made opaque per proposal, so that comparisons with it are not hoisted out of the loop.  EVLOOP: the two
+// evaluations of a proposal run as a loop over one inlined evaluator (1) or as two inlined copies (0).
+#ifndef MW_K_ZERO
+#define MW_K_ZERO 1
+#endif
+#ifndef MW_K_LANE
+#define MW_K_LANE 0
+#endif
+#ifndef MW_K_EVLOOP
+#define MW_K_EVLOOP 0
+#endif
 #define MW_NONE 0xFFFFFFFFu
 // log entry, u32 words: what a decision changed (flags = 0: nothing)
 enum { ML_FLAGS = 0, ML_BIG1, ML_SMALL1, ML_ID1, ML_BIG2, ML_SMALL2, ML_ID2, ML_DSLOT, ML_WCLR, ML_WSET, ML_WORDS = 12 };
@@ -399,15 +413,27 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     if (nev) {
         int delta[MAXT + 1];
 #pragma unroll
+#if MW_K_ZERO
+        for (int t = 0; t <= MAXT; ++t) asm volatile("v_mov_b32 %0, 0" : "=v"(delta[t]));   // (zeroed by an instruction of its own: hipcc otherwise may
+                                                                                             //  keep a zero tuple alive across the whole loop -- in scratch)
+#else
         for (int t = 0; t <= MAXT; ++t) delta[t] = 0;
+#endif
+        EvScal es = {0, 0};
+#if MW_K_EVLOOP
 #pragma nounroll
+#else
+#pragma unroll
+#endif
         for (int ev = 0; ev < 2; ++ev) {
             const Cls c = ev ? cB : cA;
-            eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta, nullptr, nullptr, &guard);
+            eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta, es, nullptr, nullptr, &guard);
         }
         fcm_lane_guard<MAXT>(delta, guard);
+        if (lane == 2) R.myd = es.d1;   // levels 1 and 2: node and arc counts of the two split graphs (scalars)
+        if (lane == 3 && MAXT >= 2) R.myd = es.d2;
 #pragma unroll
-        for (int tq = 1; tq <= MAXT; ++tq) {
+        for (int tq = 3; tq <= MAXT; ++tq) {
             const int sum = wave_sum_i32(delta[tq]);
             if (lane == tq + 1) R.myd = sum;
         }
@@ -563,7 +589,9 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // (a fresh copy of the lane id per proposal: comparisons with it are recomputed where they are used -- one VALU each --
         // instead of being hoisted out of the loop into SGPR pairs that are then spilled and reloaded)
         int lane = lane_id;
-        // asm volatile("" : "+v"(lane));
+#if MW_K_LANE
+        asm volatile("" : "+v"(lane));
+#endif
         if (ti >= 32u) {
             mw_fill_table(smem, wv, q);
             ti = 0u;
