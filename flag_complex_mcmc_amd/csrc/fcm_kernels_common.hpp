@@ -663,7 +663,7 @@ struct Wide {
     int NW;
 };
 // u64 words of dynamic LDS a workgroup needs for local sets of up to 64*NW vertices
-__host__ __device__ inline unsigned fcm_lds_words(int NW)
+__host__ __device__ constexpr inline unsigned fcm_lds_words(int NW)
 {
     if (NW <= 1) return 3u * 64u;  // (64 spare) + Hp + the arc list of walk_nodes
     return 64u * NW * NW + 12u + FCM_WIDE_LEVELS * 8u + 16u + FCM_WIDE_LEVELS + 32u * NW;

@@ -85,10 +85,12 @@ enum { MX_FLAGS = 0, MX_WCLR, MX_WSET, MX_BCLR, MX_BSET, MX_OCLR, MX_OSET, MX_DS
 #define MW_VIS_OFF 41u
 #define MW_TBL_WORDS 14u
 #define MW_WAVE_WORDS (128u + 16u * MW_TBL_WORDS)
-__host__ __device__ inline unsigned fcm_mw_lds_words(int NW, int W)
+__host__ __device__ constexpr inline unsigned fcm_mw_lds_words(int NW, int W)
 {
     return MW_SHARED_WORDS + 12u * W + (unsigned)W * MW_WAVE_WORDS + fcm_lds_words(NW < 2 ? 2 : NW);
 }
+// 4096 chains at W = 2 are all resident only if 16 workgroups fit the 160 KiB of a CU: 10 KiB each
+static_assert(fcm_mw_lds_words(2, 2) * 8u <= 10240u, "the W = 2 workgroup must stay within 10 KiB of LDS (16 per CU)");
 
 __device__ __forceinline__ void mw_barrier()   // orders LDS only
 {
@@ -430,12 +432,18 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta, es, nullptr, nullptr, &guard);
         }
         fcm_lane_guard<MAXT>(delta, guard);
-        if (lane == 2) R.myd = es.d1;   // levels 1 and 2: node and arc counts of the two split graphs (scalars)
-        if (lane == 3 && MAXT >= 2) R.myd = es.d2;
+        R.myd = lane_in(4ull) ? es.d1 : R.myd;   // levels 1 and 2: node and arc counts of the two split graphs (scalars)
+        if (MAXT >= 2) R.myd = lane_in(8ull) ? es.d2 : R.myd;
+        // the deeper levels: wave sums by DPP adds, the levels' chains interleaved step by step (no wait states between
+        // the dependent steps of one chain)
+#define MW_SUM_STEP(ctrl, rmask) _Pragma("unroll") for (int tq = 3; tq <= MAXT; ++tq) delta[tq] += __builtin_amdgcn_update_dpp(0, delta[tq], ctrl, rmask, 0xf, false)
+        MW_SUM_STEP(0x111, 0xf); MW_SUM_STEP(0x112, 0xf); MW_SUM_STEP(0x114, 0xf); MW_SUM_STEP(0x118, 0xf);
+        MW_SUM_STEP(0x142, 0xa); MW_SUM_STEP(0x143, 0xc);
+#undef MW_SUM_STEP
 #pragma unroll
         for (int tq = 3; tq <= MAXT; ++tq) {
-            const int sum = wave_sum_i32(delta[tq]);
-            if (lane == tq + 1) R.myd = sum;
+            const int sum = __builtin_amdgcn_readlane(delta[tq], 63);
+            R.myd = lane_in(1ull << (tq + 1)) ? sum : R.myd;
         }
         if (guard.tripped) R.sus |= 256u;   // a local count may have passed 2^31: refuse rather than wrap
     }
