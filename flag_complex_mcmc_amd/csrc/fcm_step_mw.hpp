@@ -68,17 +68,10 @@ enum { ML_FLAGS = 0, ML_BIG1, ML_SMALL1, ML_ID1, ML_BIG2, ML_SMALL2, ML_ID2, ML_
 enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SEED = 10, MC_SAMPLED0 = 12, MC_CUM0 = 14, MC_CUM1 = 16,
        MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_XW = 28, MC_WORDS = 30 };
 
-// result of an exact run, u32 words in the wave's LDS
-enum { MX_FLAGS = 0, MX_WCLR, MX_WSET, MX_BCLR, MX_BSET, MX_OCLR, MX_OSET, MX_DSLOT, MX_DNEW, MX_ADDK, MX_ID1, MX_BIG1, MX_SMALL1, MX_ID2,
-       MX_BIG2, MX_SMALL2, MX_SUS, MX_WORDS = 32 };   // + myd[16] as u64 behind
-#define MXF_NONEMPTY 1u
-#define MXF_DMOVE 2u
-#define MXF_WIDE 4u
-#define MXF_BIG 8u
-
 // LDS map in u64 words:
 //   shared    cnt[8] | bmin[8] | bmax[8] | ctl[2] | ctx[15] | vis[8] | log[2W][6]     (<= 8 count entries: tmax <= 6)
-//   per wave  Hp[64] | arc list[64] | draw table: 32 entries of 14 u32 [224]   (the arc list doubles as the exact run's result)
+//   per wave  Hp[64] | arc list[64] | draw table: 32 entries of 14 u32 [224]   (the entry of the proposal being run doubles as
+//             its staging record; the arc list as the exact run's per-lane results)
 //   wide evaluator (one: only the token holder runs it)
 #define MW_SHARED_WORDS 49u
 #define MW_CTX_OFF 26u
@@ -147,23 +140,35 @@ __device__ __forceinline__ MwChain mw_chain_from_lds(const u32 *ctx, int lane)
     return C;
 }
 
-// what a run of a proposal leaves behind (wave-uniform unless noted)
-struct MwProp {
-    u32 nonempty, is_dmove, used_wide, big_set, need_exact;   // 0 / 1
-    u32 wid_clr, wid_set, bit_clr, bit_set, w_clr, w_set, dslot, dnew, add_k;
-    u32 id1, big1, small1, id2, big2, small2, cx0, cx1, sus, snap;
-    u32 Lv1, Lv2;       // per lane: the local vertex lists the run read
-                        // (w_clr, w_set: the bitmap words the commit rewrites, as the builds read them)
-    int myd;            // per lane: lane d holds the change of count[d] (32 bits: fcm_lane_guard / the wide evaluator's own check)
+// What a run of a proposal leaves behind.  The wave-uniform part (MwRec) is written to the wave's staging words in LDS
+// *before* the evaluations and read back after them (SR_* words; words 0..9 are the log entry but for its ACCEPTED
+// bit): kept in SGPRs it would be live across the evaluations, where at 80 SGPRs it is spilled and reloaded.
+struct MwRec {
+    u32 nonempty, is_dmove, used_wide, big_set;   // 0 / 1
+    u32 wid_clr, wid_set, bit_clr, bit_set, dslot, dnew, add_k;
+    u32 id1, big1, small1, id2, big2, small2, cx0, cx1, sus;
 };
-
-// the log entry of a proposal, all but its ACCEPTED bit, into the wave's staging words (lane 0 writes: scalars)
-__device__ __forceinline__ void mw_stage(u32 *stage, const MwProp &R, int lane)
+enum { SR_FLAGS = 0, SR_BIG1, SR_SMALL1, SR_ID1, SR_BIG2, SR_SMALL2, SR_ID2, SR_DSLOT, SR_WCLR, SR_WSET, SR_CX0, SR_CX1, SR_SUS, SR_WORDS };
+// SR_FLAGS: nonempty<<0 | dmove<<1 | used_wide<<2 | big_set<<3 | add_k<<8 (12 bits) | clr bit index<<20 | set bit index<<25
+#define SRF_NONEMPTY 1u
+#define SRF_DMOVE 2u
+#define SRF_WIDE 4u
+#define SRF_BIG 8u
+struct MwOut {
+    u32 need_exact, snap;   // wave-uniform
+    u32 Lv1, Lv2;           // per lane: the local vertex lists the run read
+    u32 w_clr, w_set;       // per lane (all lanes alike): the two bitmap words the commit rewrites, as read beside the builds
+    int myd;                // per lane: lane d holds the change of count[d] (32 bits: fcm_lane_guard / the wide evaluator's own check)
+};
+__device__ __forceinline__ void mw_stage(u32 *stage, const MwRec &R, int lane)
 {
     if (lane == 0) {
-        *(uint4 *)(stage + 0) = make_uint4(R.is_dmove << 1, R.big1, R.small1, R.id1);
+        const u32 fl = R.nonempty | (R.is_dmove << 1) | (R.used_wide << 2) | (R.big_set << 3) | ((R.add_k & 0xFFFu) << 8)
+                       | ((u32)(R.bit_clr ? __ffs((int)R.bit_clr) - 1 : 0) << 20) | ((u32)(R.bit_set ? __ffs((int)R.bit_set) - 1 : 0) << 25);
+        *(uint4 *)(stage + 0) = make_uint4(fl, R.big1, R.small1, R.id1);
         *(uint4 *)(stage + 4) = make_uint4(R.big2, R.small2, R.id2, R.dslot);
-        *(uint2 *)(stage + 8) = make_uint2(R.wid_clr, R.wid_set);
+        *(uint4 *)(stage + 8) = make_uint4(R.wid_clr, R.wid_set, R.cx0, R.cx1);
+        stage[SR_SUS] = R.sus;
     }
     wave_sync();
 }
@@ -174,9 +179,10 @@ __device__ __forceinline__ void mw_stage(u32 *stage, const MwProp &R, int lane)
 // else sets need_exact and is left to the exact run.  EXACT = true: the whole of it (candidate search to the end, wide
 // evaluator), on a state nobody else changes meanwhile.
 template <int MAXT, bool ROWS128, bool EXACT>
-__device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds, int maxnw, u32 tv, u64 tt, u32 gchain, u64 seed, int lane, MwProp &R,
-                                       u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u, u64 guard_limit = 0x7FFFFFFFull)
+__device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds, int maxnw, u32 tv, u64 tt, u32 gchain, u64 seed, int lane, MwOut &O,
+                                       u32 *stage, u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u, u64 guard_limit = 0x7FFFFFFFull)
 {
+    MwRec R;
     const int tmax = MAXT;
     // The snap point (hot path only): between the static loads of the proposal (table entry, vertex lists) and its first
     // load of mutable state.  The wave's earlier commit stores have completed by then (s_waitcnt vmcnt(0), which the
@@ -187,16 +193,16 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             if (!snapped) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_store(&vis[wv], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                R.snap = mw_vis_min(vis, W, lane);
+                O.snap = mw_vis_min(vis, W, lane);
                 snapped = true;
             }
         }
     };
-    R.nonempty = R.is_dmove = R.used_wide = R.big_set = R.need_exact = 0u;
-    R.wid_clr = R.wid_set = MW_NONE; R.bit_clr = R.bit_set = 0u; R.w_clr = R.w_set = 0u; R.dslot = MW_NONE; R.dnew = 0u; R.add_k = 0u;
+    R.nonempty = R.is_dmove = R.used_wide = R.big_set = O.need_exact = 0u;
+    R.wid_clr = R.wid_set = MW_NONE; R.bit_clr = R.bit_set = 0u; O.w_clr = O.w_set = 0u; R.dslot = MW_NONE; R.dnew = 0u; R.add_k = 0u;
     R.id1 = R.big1 = R.small1 = R.id2 = R.big2 = R.small2 = R.cx0 = R.cx1 = MW_NONE; R.sus = 0u;
-    R.Lv1 = MW_NONE; R.Lv2 = MW_NONE;
-    R.myd = 0; R.snap = 0u;
+    O.Lv1 = MW_NONE; O.Lv2 = MW_NONE;
+    O.myd = 0; O.snap = 0u;
     FcmGuard guard = {guard_limit, 0u};
     const int move = (int)(rdlane(tv, 0) & 0xFFu);
     const u32 coin = (rdlane(tv, 0) >> 8) & 1u;
@@ -221,9 +227,9 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             R.id1 = (u32)idx; R.big1 = e1.big; R.small1 = e1.small;
             const u32 wid_bs = e1.big * stride32 + (e1.small >> 5), wid_sb = e1.small * stride32 + (e1.big >> 5);   // the words of big->small, small->big
             if (k + 2 <= WAVE) {
-                R.Lv1 = load_list(C.nb, e1.nb_off, k, e1.big, e1.small, lane);
+                O.Lv1 = load_list(C.nb, e1.nb_off, k, e1.big, e1.small, lane);
                 snap_point();
-                const u64 myH = mw_build<ROWS128>(rr, stride32, R.Lv1, k + 2, lane);
+                const u64 myH = mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
                 const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
                 const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);  // big->small, small->big
                 if (ab == ba) {
@@ -242,12 +248,12 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             }
             if (go_wide) {
                 if constexpr (!EXACT) {
-                    R.need_exact = 1u;
+                    O.need_exact = 1u;
                 } else {
                     fres = 0;
                     if (k + 2 > 64 * maxnw && C.xw && k + 2 <= 64 * FCM_XW_MAXNW) {   // 257..1024 local vertices
                         const int res = xw_flip(C.xw, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
-                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? xw_count(C.xw, lane - 1) : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
+                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? xw_count(C.xw, lane - 1) : 0ll; O.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                         wave_sync();
                         R.used_wide = 1u;
                         if (res < 0) R.sus |= 1u;
@@ -256,7 +262,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                         const Wide Wd = wide_carve(wide_lds, maxnw);
                         wide_zero_counts(Wd, lane);
                         const int res = wide_flip(Wd, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
-                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
+                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; O.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                         wave_sync();
                         R.used_wide = 1u;
                         if (res < 0) R.sus |= 1u;
@@ -266,7 +272,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     }
                 }
             }
-            if (fres > 0 && !R.need_exact) {
+            if (fres > 0 && !O.need_exact) {
                 R.nonempty = 1u;
                 const u32 cf = fres == 1 ? e1.big : e1.small, ct = fres == 1 ? e1.small : e1.big;
                 R.wid_clr = fres == 1 ? wid_bs : wid_sb; R.bit_clr = 1u << (ct & 31u);
@@ -299,13 +305,13 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
         bool found = false;
         u32 rfwd = 0u;
 #pragma nounroll
-        for (int ci = 0; ci < (EXACT ? WAVE : 3) && !found && !R.need_exact; ++ci) {
+        for (int ci = 0; ci < (EXACT ? WAVE : 3) && !found && !O.need_exact; ++ci) {
             if (ci < 2) {
                 const u32 cv = rdlane(tv, 12 + ci);
                 cand = cv == MW_NONE ? ~0ull : (u64)cv;
                 if (ci == 0) R.cx0 = cv; else R.cx1 = cv;
             } else if constexpr (!EXACT) {
-                R.need_exact = 1u;
+                O.need_exact = 1u;
                 break;
             } else if ((ci & 1) == 0) {  // Philox block sub = ci/2 + 1: two candidates
                 u32 v[4];
@@ -324,22 +330,22 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                 u32 f = 0u, bwd = 0u;
                 if (ck + 2 <= WAVE) {
                     if (ci == 0) {
-                        R.Lv2 = Lv2pre;
+                        O.Lv2 = Lv2pre;
                     } else {
-                        R.Lv2 = load_list(C.nb, e2.nb_off, ck, e2.big, e2.small, lane);
+                        O.Lv2 = load_list(C.nb, e2.nb_off, ck, e2.big, e2.small, lane);
                     }
-                    HB = mw_build<ROWS128>(rr, stride32, R.Lv2, ck + 2, lane);
+                    HB = mw_build<ROWS128>(rr, stride32, O.Lv2, ck + 2, lane);
                     f = (u32)(rdlane64(HB, ck + 1) >> ck) & 1u;
                     bwd = (u32)(rdlane64(HB, ck) >> (ck + 1)) & 1u;
                 } else {
                     if constexpr (!EXACT) {
-                        R.need_exact = 1u;
+                        O.need_exact = 1u;
                         break;
                     } else {  // wide candidate: look at its two words directly
                         const u32 wf = mw_uni(C.rows[e2.big * stride32 + (e2.small >> 5)]), wb = mw_uni(C.rows[e2.small * stride32 + (e2.big >> 5)]);
                         f = (wf >> (e2.small & 31u)) & 1u;
                         bwd = (wb >> (e2.big & 31u)) & 1u;
-                        R.Lv2 = MW_NONE;
+                        O.Lv2 = MW_NONE;
                     }
                 }
                 if (!(f | bwd)) R.sus |= 1u;
@@ -355,15 +361,15 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             go_wide = dk + 2 > WAVE || rk + 2 > WAVE;
             bool okd = true;
             if (!go_wide) {
-                R.Lv1 = load_list(C.nb, e1.nb_off, dk, e1.big, e1.small, lane);
-                HA = mw_build<ROWS128>(rr, stride32, R.Lv1, dk + 2, lane);
+                O.Lv1 = load_list(C.nb, e1.nb_off, dk, e1.big, e1.small, lane);
+                HA = mw_build<ROWS128>(rr, stride32, O.Lv1, dk + 2, lane);
                 // (1) remove the direction the coin picks from the reciprocal pair
                 const u32 ab = (u32)((rdlane64(HA, dk + 1) >> dk) & 1ull), ba = (u32)((rdlane64(HA, dk) >> (dk + 1)) & 1ull);
                 okd = (ab & ba) != 0u;
                 const int iu = coin ? dk : dk + 1, iv = coin ? dk + 1 : dk;
                 cA = classify(HA, iv, iu);
                 // (2) add the reverse of the single edge on the graph without the removed one
-                const u64 mf = ballot(lane < rk + 2 && R.Lv2 == dfrom), mt = ballot(lane < rk + 2 && R.Lv2 == dto);
+                const u64 mf = ballot(lane < rk + 2 && O.Lv2 == dfrom), mt = ballot(lane < rk + 2 && O.Lv2 == dto);
                 if (mf && mt) {
                     const int fi = __ffsll((long long)mf) - 1, tix = __ffsll((long long)mt) - 1;
                     if (lane == tix) HB &= ~(1ull << fi);
@@ -376,12 +382,12 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             }
             if (go_wide) {
                 if constexpr (!EXACT) {
-                    R.need_exact = 1u;
+                    O.need_exact = 1u;
                 } else if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
                     if (C.xw && dk + 2 <= 64 * FCM_XW_MAXNW && rk + 2 <= 64 * FCM_XW_MAXNW) {
                         okd = xw_del(C.xw, C.rows, stride32, C.nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
                         xw_add(C.xw, C.rows, stride32, C.nb, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax, true);
-                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? xw_count(C.xw, lane - 1) : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
+                        { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? xw_count(C.xw, lane - 1) : 0ll; O.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                         wave_sync();
                         R.used_wide = 1u;
                     } else {
@@ -392,7 +398,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     wide_zero_counts(Wd, lane);
                     okd = wide_del(Wd, C.rows, stride32, C.nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
                     wide_add(Wd, C.rows, stride32, C.nb, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax);
-                    { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; R.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
+                    { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; O.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                     wave_sync();
                     R.used_wide = 1u;
                 }
@@ -409,9 +415,11 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     // the two bitmap words a commit rewrites, read here -- lines the builds have just touched -- so that the commit is
     // two plain stores.  Issued last: the round trip runs beside the wait for the token instead of in front of it.
     if (R.nonempty) {
-        R.w_clr = C.rows[R.wid_clr];
-        R.w_set = C.rows[R.wid_set];
+        O.w_clr = C.rows[R.wid_clr];
+        O.w_set = C.rows[R.wid_set];
     }
+    R.dnew = R.id2;
+    mw_stage(stage, R, lane);   // the record, before the evaluations: nothing of it stays in registers across them
     if (nev) {
         int delta[MAXT + 1];
 #pragma unroll
@@ -432,8 +440,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta, es, nullptr, nullptr, &guard);
         }
         fcm_lane_guard<MAXT>(delta, guard);
-        R.myd = lane_in(4ull) ? es.d1 : R.myd;   // levels 1 and 2: node and arc counts of the two split graphs (scalars)
-        if (MAXT >= 2) R.myd = lane_in(8ull) ? es.d2 : R.myd;
+        O.myd = lane_in(4ull) ? es.d1 : O.myd;   // levels 1 and 2: node and arc counts of the two split graphs (scalars)
+        if (MAXT >= 2) O.myd = lane_in(8ull) ? es.d2 : O.myd;
         // the deeper levels: wave sums by DPP adds, the levels' chains interleaved step by step (no wait states between
         // the dependent steps of one chain)
 #define MW_SUM_STEP(ctrl, rmask) _Pragma("unroll") for (int tq = 3; tq <= MAXT; ++tq) delta[tq] += __builtin_amdgcn_update_dpp(0, delta[tq], ctrl, rmask, 0xf, false)
@@ -443,18 +451,19 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
 #pragma unroll
         for (int tq = 3; tq <= MAXT; ++tq) {
             const int sum = __builtin_amdgcn_readlane(delta[tq], 63);
-            R.myd = lane_in(1ull << (tq + 1)) ? sum : R.myd;
+            O.myd = lane_in(1ull << (tq + 1)) ? sum : O.myd;
         }
-        if (guard.tripped) R.sus |= 256u;   // a local count may have passed 2^31: refuse rather than wrap
+        if (guard.tripped) { if (lane == 0) stage[SR_SUS] |= 256u; wave_sync(); }   // a local count may have passed 2^31: refuse rather than wrap
     }
 }
 
-// ---- out of line: the exact run.  Context from LDS, result to the wave's LDS (MX_*, myd behind it).
+// ---- out of line: the exact run.  Context from LDS; the record goes to the staging words like the hot path's, the
+// per-lane results (count changes, the two bitmap words) to the arc list's place.
 template <int MAXT, bool ROWS128>
-__device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 tv, u32 q)
+__device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 tv, u32 q, u32 stage_off)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    wv = mw_uni(wv); q = mw_uni(q);
+    wv = mw_uni(wv); q = mw_uni(q); stage_off = mw_uni(stage_off);
     const u32 *ctx = (const u32 *)(smem + MW_CTX_OFF);
     const u32 cv = lane < MC_WORDS ? ctx[lane] : 0u;
     const u32 W = rdlane(cv, MC_W);
@@ -464,18 +473,13 @@ __device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 t
     u64 *wide_lds = smem + MW_SHARED_WORDS + 12u * W + (size_t)W * MW_WAVE_WORDS;
     const u64 seed = (u64)rdlane(cv, MC_SEED) | ((u64)rdlane(cv, MC_SEED + 1) << 32);
     const u64 sampled0 = (u64)rdlane(cv, MC_SAMPLED0) | ((u64)rdlane(cv, MC_SAMPLED0 + 1) << 32);
-    MwProp R;
-    mw_run<MAXT, ROWS128, true>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, R, nullptr, 0u, 0u, 0u,
+    MwOut O;
+    mw_run<MAXT, ROWS128, true>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, O, (u32 *)smem + stage_off, nullptr, 0u, 0u, 0u,
                                 (u64)rdlane(cv, MC_GUARD) | ((u64)rdlane(cv, MC_GUARD + 1) << 32));
     u32 *out = (u32 *)(mine_lds + 64);
-    if (lane == 0) {
-        out[MX_FLAGS] = (R.nonempty ? MXF_NONEMPTY : 0u) | (R.is_dmove ? MXF_DMOVE : 0u) | (R.used_wide ? MXF_WIDE : 0u) | (R.big_set ? MXF_BIG : 0u);
-        out[MX_WCLR] = R.wid_clr; out[MX_WSET] = R.wid_set; out[MX_BCLR] = R.bit_clr; out[MX_BSET] = R.bit_set;
-        out[MX_OCLR] = R.w_clr; out[MX_OSET] = R.w_set; out[MX_DSLOT] = R.dslot; out[MX_DNEW] = R.dnew; out[MX_ADDK] = R.add_k;
-        out[MX_ID1] = R.id1; out[MX_BIG1] = R.big1; out[MX_SMALL1] = R.small1;
-        out[MX_ID2] = R.id2; out[MX_BIG2] = R.big2; out[MX_SMALL2] = R.small2; out[MX_SUS] = R.sus;
-    }
-    if (lane < 16) ((int *)(out + MX_WORDS))[lane] = R.myd;
+    if (lane < 16) out[lane] = (u32)O.myd;
+    if (lane == 16) out[16] = O.w_clr;
+    if (lane == 17) out[17] = O.w_set;
     wave_sync();
 }
 
@@ -612,48 +616,50 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // those from snap on are held against this proposal's reads before it is decided.
         // the oldest undecided proposal is what the chain's other waves end up waiting for: let it go first on its SIMD
         if (mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == q) __builtin_amdgcn_s_setprio(2);
-        MwProp R;
+        MwOut O;
+        u32 *stage = (u32 *)T + (ti - 1u) * MW_TBL_WORDS;   // the table entry just taken into `tv`: its place holds the staging record now
         MW_T(t_snap);
-        mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, R, vis, wv, q, W, guard_limit);
-        const u32 snap = R.snap;
+        mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, O, stage, vis, wv, q, W, guard_limit);
+        const u32 snap = O.snap;
         MW_T(t_run);
 
-        // ---- before the token: everything the decision can have ready
-        u32 *stage = (u32 *)(mine_lds + 64);               // (the arc list's place: free between evaluations)
-        mw_stage(stage, R, lane);
-        // the commit's two stores (one value twice if both changes fall into one word: double-edge move only)
-        u32 nclr = R.w_clr & ~R.bit_clr, nset = R.w_set | R.bit_set;
-        if (R.wid_clr == R.wid_set) { nclr |= R.bit_set; nset = nclr; }
+        // ---- before the token: everything the decision can have ready.  sv = the staged record (lane i = word i)
+        u32 sv = lane < SR_WORDS ? stage[lane] : 0u;
+        u32 w_clr = O.w_clr, w_set = O.w_set;
 
         // ---- in-order decision.  While waiting for the token, look at the decisions taken since `snap` as they are
         // published: by the time head == q only the last of them is left.
-        bool hit = R.need_exact != 0u;
-        u32 c = snap;
-        for (;;) {
-            const u32 h = mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // h <= q
-            while (c < h && !hit) {
-                const u32 ev = lane < ML_WORDS ? logL[(c & ring) * ML_WORDS + lane] : 0u;
-                ++c;
-                const u32 fl = rdlane(ev, ML_FLAGS);
-                if (!(fl & ML_ACCEPTED)) continue;
-                const u32 b1 = rdlane(ev, ML_BIG1), s1 = rdlane(ev, ML_SMALL1), i1 = rdlane(ev, ML_ID1);
-                const u32 wc = rdlane(ev, ML_WCLR), ws = rdlane(ev, ML_WSET);
-                hit = mw_inside(R.Lv1, b1, s1) || mw_inside(R.Lv2, b1, s1) || i1 == R.cx0 || i1 == R.cx1
-                      || wc == R.wid_clr || wc == R.wid_set || ws == R.wid_clr || ws == R.wid_set;
-                if (fl & ML_DMOVE) {
-                    const u32 b2 = rdlane(ev, ML_BIG2), s2 = rdlane(ev, ML_SMALL2), i2 = rdlane(ev, ML_ID2);
-                    hit = hit || mw_inside(R.Lv1, b2, s2) || mw_inside(R.Lv2, b2, s2) || i2 == R.cx0 || i2 == R.cx1 || rdlane(ev, ML_DSLOT) == R.dslot;
+        bool hit = O.need_exact != 0u;
+        {
+            const u32 cx0 = rdlane(sv, SR_CX0), cx1 = rdlane(sv, SR_CX1), dslot = rdlane(sv, SR_DSLOT);
+            const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
+            u32 c = snap;
+            for (;;) {
+                const u32 h = mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // h <= q
+                while (c < h && !hit) {
+                    const u32 ev = lane < ML_WORDS ? logL[(c & ring) * ML_WORDS + lane] : 0u;
+                    ++c;
+                    const u32 fl = rdlane(ev, ML_FLAGS);
+                    if (!(fl & ML_ACCEPTED)) continue;
+                    const u32 b1 = rdlane(ev, ML_BIG1), s1 = rdlane(ev, ML_SMALL1), i1 = rdlane(ev, ML_ID1);
+                    const u32 wc = rdlane(ev, ML_WCLR), ws = rdlane(ev, ML_WSET);
+                    hit = mw_inside(O.Lv1, b1, s1) || mw_inside(O.Lv2, b1, s1) || i1 == cx0 || i1 == cx1
+                          || wc == wid_clr || wc == wid_set || ws == wid_clr || ws == wid_set;
+                    if (fl & ML_DMOVE) {
+                        const u32 b2 = rdlane(ev, ML_BIG2), s2 = rdlane(ev, ML_SMALL2), i2 = rdlane(ev, ML_ID2);
+                        hit = hit || mw_inside(O.Lv1, b2, s2) || mw_inside(O.Lv2, b2, s2) || i2 == cx0 || i2 == cx1 || rdlane(ev, ML_DSLOT) == dslot;
+                    }
                 }
-            }
-            if (h == q) break;
+                if (h == q) break;
 #ifdef MW_STAMP
-            st_acc[7] += 1;
+                st_acc[7] += 1;
 #endif
-            // not yet: doze by how far off the token is (a decision takes several hundred cycles)
-            const u32 dist = q - h;
-            if (dist >= 4u) __builtin_amdgcn_s_sleep(10);
-            else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
-            else __builtin_amdgcn_s_sleep(1);
+                // not yet: doze by how far off the token is (a decision takes several hundred cycles)
+                const u32 dist = q - h;
+                if (dist >= 4u) __builtin_amdgcn_s_sleep(10);
+                else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
+                else __builtin_amdgcn_s_sleep(1);
+            }
         }
         MW_T(t_token);
         __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
@@ -661,20 +667,13 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             // under the token nobody else can commit; once every earlier commit is in memory too, run it again, all of it
             n_redo += 1u;
             while (mw_vis_min(vis, W, lane) < q) __builtin_amdgcn_s_sleep(1);
-            mw_exact_call<MAXT, ROWS128>(smem, wv, tv, q);
+            mw_exact_call<MAXT, ROWS128>(smem, wv, tv, q, (u32)(stage - (u32 *)smem));
             const u32 *out = (const u32 *)(mine_lds + 64);
-            const u32 xv = lane < MX_WORDS ? out[lane] : 0u;
-            if (lane < 16) R.myd = ((const int *)(out + MX_WORDS))[lane];
-            const u32 fl = rdlane(xv, MX_FLAGS);
-            R.nonempty = fl & 1u; R.is_dmove = (fl >> 1) & 1u; R.used_wide = (fl >> 2) & 1u; R.big_set = (fl >> 3) & 1u;
-            R.wid_clr = rdlane(xv, MX_WCLR); R.wid_set = rdlane(xv, MX_WSET); R.bit_clr = rdlane(xv, MX_BCLR); R.bit_set = rdlane(xv, MX_BSET);
-            R.w_clr = rdlane(xv, MX_OCLR); R.w_set = rdlane(xv, MX_OSET); R.dslot = rdlane(xv, MX_DSLOT); R.dnew = rdlane(xv, MX_DNEW);
-            R.add_k = rdlane(xv, MX_ADDK); R.id1 = rdlane(xv, MX_ID1); R.big1 = rdlane(xv, MX_BIG1); R.small1 = rdlane(xv, MX_SMALL1);
-            R.id2 = rdlane(xv, MX_ID2); R.big2 = rdlane(xv, MX_BIG2); R.small2 = rdlane(xv, MX_SMALL2); R.sus = rdlane(xv, MX_SUS);
+            const u32 xv = lane < 18 ? out[lane] : 0u;
+            O.myd = lane < 16 ? (int)xv : 0;
+            w_clr = rdlane(xv, 16); w_set = rdlane(xv, 17);
+            sv = lane < SR_WORDS ? stage[lane] : 0u;
             wave_sync();
-            mw_stage(stage, R, lane);
-            nclr = R.w_clr & ~R.bit_clr; nset = R.w_set | R.bit_set;
-            if (R.wid_clr == R.wid_set) { nclr |= R.bit_set; nset = nclr; }
         }
 
         // ---- Bounds::check; accept or drop (src/lib.rs:185-191) -- under the token, as little as possible: LDS only.
@@ -683,23 +682,31 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         MW_T(t_redo);
         const bool l16 = lane < 8;
         const u64 cnt = l16 ? cntL[lane] : 0ull, bmin = l16 ? bminL[lane] : 0ull, bmax = l16 ? bmaxL[lane] : ~0ull;
-        const u32 sv = lane < ML_WORDS ? stage[lane] : (lane == 16 ? ctl[1] : 0u);   // the staged log entry; lane 16: inside the bounds?
-        const u32 in_bounds = rdlane(sv, 16);
-        const u64 ncnt = cnt + (u64)(long long)R.myd;
+        const u32 in_bounds = mw_uni(ctl[1]);
+        const u32 flg = rdlane(sv, SR_FLAGS);
+        const u32 nonempty = flg & SRF_NONEMPTY, is_dmove = (flg >> 1) & 1u;
+        const u64 ncnt = cnt + (u64)(long long)O.myd;
         const u32 within = ballot(ncnt < bmin || ncnt > bmax) == 0ull ? 1u : 0u;
-        const u32 commit = R.nonempty & within;
+        const u32 commit = nonempty & within;
         MW_T(t_dec1);
         if (commit && l16) cntL[lane] = ncnt;
-        if (lane < ML_WORDS) logL[(q & ring) * ML_WORDS + lane] = lane == 0 ? (sv | commit) : sv;
+        if (lane < ML_WORDS) logL[(q & ring) * ML_WORDS + lane] = lane == 0 ? (commit | (is_dmove << 1)) : sv;
         if (commit && !in_bounds && lane == 0) ctl[1] = 1u;
         MW_T(t_dec2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the log entry and the counts
         __hip_atomic_store(&ctl[0], q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_s_setprio(0);
-        if (commit && lane == 0) {
-            C.rows[R.wid_clr] = nclr;
-            C.rows[R.wid_set] = nset;
-            if (R.is_dmove) C.dbl[R.dslot] = R.dnew;
+        if (commit) {
+            // the commit's stores (one value twice if both changes fall into one word: double-edge move only)
+            const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
+            const u32 bit_clr = 1u << ((flg >> 20) & 31u), bit_set = 1u << ((flg >> 25) & 31u);
+            u32 nclr = w_clr & ~bit_clr, nset = w_set | bit_set;
+            if (wid_clr == wid_set) { nclr |= bit_set; nset = nclr; }
+            if (lane == 0) {
+                C.rows[wid_clr] = nclr;
+                C.rows[wid_set] = nset;
+                if (is_dmove) C.dbl[rdlane(sv, SR_DSLOT)] = rdlane(sv, SR_ID2);
+            }
         }
 #ifdef MW_STAMP
         {
@@ -716,16 +723,16 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 #endif
 
         // ---- the token is gone: this wave's counters (sampled += 1, src/lib.rs:185)
-        status |= R.sus;
+        status |= rdlane(sv, SR_SUS);
         mine += 1u;
-        accepted += commit | ((R.nonempty ^ 1u) & in_bounds);   // an empty transition is accepted iff the state is inside the bounds
-        n_empty += R.nonempty ^ 1u;
-        n_dmove += R.nonempty & R.is_dmove;
-        sum_k += R.add_k;
-        n_wide += R.used_wide;
-        n_big += R.big_set;
-        if (R.nonempty) {
-            if (ballot(R.myd < 0 && cnt < (u64)(-(long long)R.myd))) status |= 8u;  // reference assert, src/lib.rs:65
+        accepted += commit | ((nonempty ^ 1u) & in_bounds);   // an empty transition is accepted iff the state is inside the bounds
+        n_empty += nonempty ^ 1u;
+        n_dmove += nonempty & is_dmove;
+        sum_k += (flg >> 8) & 0xFFFu;
+        n_wide += (flg >> 2) & 1u;
+        n_big += (flg >> 3) & 1u;
+        if (nonempty) {
+            if (ballot(O.myd < 0 && cnt < (u64)(-(long long)O.myd))) status |= 8u;  // reference assert, src/lib.rs:65
             const u64 nz = ballot(l16 && ncnt != 0ull);                // flag_count never shrinks in length (src/lib.rs:72-74)
             const u32 nlen = nz ? (u32)(64 - __clzll((long long)nz)) : 0u;
             if (nlen > count_len) count_len = nlen;
