@@ -653,6 +653,8 @@ def test_multi_wave_kernel_is_selected_and_switchable(fcm, monkeypatch):
     b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.05))
     assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["waves_per_chain"] == 8         # few chains: many waves each
     assert fcm.MCMCSampler(g, b, n_chains=2048, seed=1).info["waves_per_chain"] == 4
+    assert fcm.MCMCSampler(g, b, n_chains=1024, seed=1).info["waves_per_chain"] == 8
+    assert fcm.MCMCSampler(g, b, n_chains=3000, seed=1).info["waves_per_chain"] == 2      # 3000 x 4 would not all be resident
     assert fcm.MCMCSampler(g, b, n_chains=4096, seed=1).info["waves_per_chain"] == 2      # chains x W = the chip's 8192 wave slots
     assert fcm.MCMCSampler(g, b, n_chains=2, seed=1, move_weights=fcm.MOVE_DISTRIBUTION).info["waves_per_chain"] == 1  # clique moves
     monkeypatch.setenv("FCM_MW", "1")
