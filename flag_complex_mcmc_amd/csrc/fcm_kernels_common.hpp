@@ -289,6 +289,7 @@ __device__ __forceinline__ u64 build_local_loop16(const rsrc_t rsrc, u32 stride3
 // that register and comes over with ds_bpermute (the LDS crossbar, no LDS memory).  Used by the
 // producer wave of the two-wave kernel, which has 64 VGPRs.
 // groups of four row pairs (eight rows) G0 .. G1-1, registers w[0 ..]: issue ...
+// (`sel` is opaque to the compiler, so that sel + 8q stays an addition and folds into ds_bpermute's offset field)
 template <int G, int G0, int G1, int NW>
 __device__ __forceinline__ void build128_issue(const rsrc_t rsrc, u32 Lv, u32 sel, u32 dw, int s, u32 (&w)[NW])
 {
@@ -304,35 +305,58 @@ __device__ __forceinline__ void build128_issue(const rsrc_t rsrc, u32 Lv, u32 se
         }
     }
 }
+// h |= (bit bpos of x) << POS: v_bfe, v_lshl_or (written out: hipcc would make it v_bfe, v_lshl and half a v_or3)
+template <int POS>
+__device__ __forceinline__ void build_put(u32 &h, u32 x, u32 bpos)
+{
+    const u32 b = __builtin_amdgcn_ubfe(x, bpos, 1u);
+    asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(h) : "v"(b), "n"(POS));
+}
 // ... and consume
+template <int Q, int Q0, int NW>
+__device__ __forceinline__ void build128_pair(const u32 (&w)[NW], u32 src, u32 bpos, u32 &hlo, u32 &hhi)
+{
+    const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute((int)src, (int)w[Q - Q0]);
+    const u32 x1 = (u32)__builtin_amdgcn_ds_bpermute((int)(src + 128u), (int)w[Q - Q0]);
+    if constexpr (Q < 16) { build_put<2 * Q>(hlo, x0, bpos); build_put<2 * Q + 1>(hlo, x1, bpos); }
+    else { build_put<2 * Q - 32>(hhi, x0, bpos); build_put<2 * Q + 1 - 32>(hhi, x1, bpos); }
+}
 template <int G, int G0, int G1, int NW>
 __device__ __forceinline__ void build128_consume(const u32 (&w)[NW], u32 src, u32 bpos, int s, u32 &hlo, u32 &hhi)
 {
     if constexpr (G < G1) {
         if (8 * G < s) {
-#pragma unroll
-            for (int q = 4 * G; q < 4 * G + 4; ++q) {
-                const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute((int)src, (int)w[q - 4 * G0]);
-                const u32 x1 = (u32)__builtin_amdgcn_ds_bpermute((int)(src + 128u), (int)w[q - 4 * G0]);
-                const u32 b0 = __builtin_amdgcn_ubfe(x0, bpos, 1u), b1 = __builtin_amdgcn_ubfe(x1, bpos, 1u);
-                if constexpr (G < 4) hlo |= (b0 << (2 * q)) | (b1 << (2 * q + 1));
-                else hhi |= (b0 << (2 * q - 32)) | (b1 << (2 * q + 1 - 32));
-            }
+            build128_pair<4 * G, 4 * G0, NW>(w, src, bpos, hlo, hhi);
+            build128_pair<4 * G + 1, 4 * G0, NW>(w, src, bpos, hlo, hhi);
+            build128_pair<4 * G + 2, 4 * G0, NW>(w, src, bpos, hlo, hhi);
+            build128_pair<4 * G + 3, 4 * G0, NW>(w, src, bpos, hlo, hhi);
             build128_consume<G + 1, G0, G1, NW>(w, src, bpos, s, hlo, hhi);
         }
     }
 }
+// (the registers of groups that are not read are never looked at; declaring them written by an empty asm statement
+// keeps hipcc from zeroing them on every path that skips their reads: 60 v_mov per build of 40 rows)
+template <int N>
+__device__ __forceinline__ void build_regs_any(u32 (&w)[N])
+{
+#pragma unroll
+    for (int q = 0; q < N; ++q) asm volatile("" : "=v"(w[q]));
+}
 __device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, int s, int lane)
 {
-    const u32 sel = lane >= 32 ? 4u : 0u, dw = (u32)(lane & 31) * 4u, src = (Lv >> 5) * 4u, bpos = Lv & 31u;
+    u32 sel = lane >= 32 ? 4u : 0u;
+    asm volatile("" : "+v"(sel));
+    const u32 dw = (u32)(lane & 31) * 4u, src = (Lv >> 5) * 4u, bpos = Lv & 31u;
     u32 hlo = 0u, hhi = 0u;
     {   // rows 0..47: 24 registers in flight, one round trip
         u32 w[24];   // (a group of four is consumed under the very condition it is loaded under)
+        build_regs_any(w);
         build128_issue<0, 0, 6, 24>(rsrc, Lv, sel, dw, s, w);
         build128_consume<0, 0, 6, 24>(w, src, bpos, s, hlo, hhi);
     }
     if (s > 48) {   // rows 48..63 (one pair in twenty on config 3): a second trip, the registers are free again
         u32 w[8];
+        build_regs_any(w);
         build128_issue<6, 6, 8, 8>(rsrc, Lv, sel, dw, s, w);
         build128_consume<6, 6, 8, 8>(w, src, bpos, s, hlo, hhi);
     }
