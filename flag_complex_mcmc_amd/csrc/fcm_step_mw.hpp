@@ -39,6 +39,9 @@
 // whatever the wave loads from then on; the decisions snap..q-1 -- at most 2W-1 of them, the log keeps 2W -- are held
 // against its reads.  All waves of a workgroup run on one CU and share its vector L1: workgroup scope.
 #pragma once
+#ifndef MW_PROBE
+#define MW_PROBE 0
+#endif
 
 #ifndef MW_MINW
 #define MW_MINW 8
@@ -69,13 +72,15 @@ enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SE
        MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_XW = 28, MC_WORDS = 30 };
 
 // LDS map in u64 words:
-//   shared    cnt[8] | bmin[8] | bmax[8] | ctl[2] | ctx[15] | vis[8] | log[2W][6]     (<= 8 count entries: tmax <= 6)
+//   shared    E[9]: {count, inside-the-bounds flag (entry 0), bmin, bmax} | head | ctx[15] | vis[8] | log[2W][6]
+//             (<= 8 count entries: tmax <= 6; entry 8 = {0, 0, 0, ~0} is what the lanes without a count read)
 //   per wave  Hp[64] | arc list[64] | draw table: 32 entries of 14 u32 [224]   (the entry of the proposal being run doubles as
 //             its staging record; the arc list as the exact run's per-lane results)
 //   wide evaluator (one: only the token holder runs it)
-#define MW_SHARED_WORDS 49u
-#define MW_CTX_OFF 26u
-#define MW_VIS_OFF 41u
+#define MW_SHARED_WORDS 60u
+#define MW_HEAD_OFF 36u
+#define MW_CTX_OFF 37u
+#define MW_VIS_OFF 52u
 #define MW_TBL_WORDS 14u
 #define MW_WAVE_WORDS (128u + 16u * MW_TBL_WORDS)
 __host__ __device__ constexpr inline unsigned fcm_mw_lds_words(int NW, int W)
@@ -104,10 +109,17 @@ __device__ __forceinline__ u64 mw_build(const rsrc_t rr, u32 stride32, u32 Lv, i
 // both endpoints of the pair (big, small) in the local list Lv?  (lanes beyond the list repeat its last vertex)
 __device__ __forceinline__ bool mw_inside(u32 Lv, u32 big, u32 small) { return ballot(Lv == big) != 0ull && ballot(Lv == small) != 0ull; }
 
+// LDS stores of the lanes in a literal mask, with no predicate to compute or keep.  Only where all 64 lanes are active
+// (the top level of the wave loop: its branches are wave-uniform).  LDS executes a wave's operations in order, so a
+// later store of the same wave (the head) is seen by nobody before these are.
+#define MW_LDS_ST32(addr, val, MASK) asm volatile("s_mov_b64 exec, " MASK "\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(val) : "memory")
+#define MW_LDS_ST64(addr, val, MASK) asm volatile("s_mov_b64 exec, " MASK "\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(val) : "memory")
+__device__ __forceinline__ u32 mw_lds_addr(const void *p) { return (u32)(size_t)(__attribute__((address_space(3))) const char *)p; }
+
 // min over the waves of vis[]: every proposal below it is visible to what this wave loads from now on (acquire)
 __device__ __forceinline__ u32 mw_vis_min(const u32 *vis, u32 W, int lane)
 {
-    u32 v = lane < 16 ? __hip_atomic_load(&vis[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : MW_NONE;   // (entries >= W hold MW_NONE)
+    u32 v = __hip_atomic_load(&vis[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // every row of 16 lanes reads all of it (entries >= W hold MW_NONE)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     v = min(v, (u32)__builtin_amdgcn_update_dpp((int)MW_NONE, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
     v = min(v, (u32)__builtin_amdgcn_update_dpp((int)MW_NONE, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
@@ -229,7 +241,12 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             if (k + 2 <= WAVE) {
                 O.Lv1 = load_list(C.nb, e1.nb_off, k, e1.big, e1.small, lane);
                 snap_point();
+#if MW_PROBE == 1   // (instruction-cost probe, tools/probe_costs.sh: a flip builds its masks twice)
+                u64 myH = mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
+                { u32 z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); u32 Lz = O.Lv1; asm volatile("" : "+v"(Lz)); myH |= mw_build<ROWS128>(rr, stride32, Lz, k + 2, lane) & (u64)z; }
+#else
                 const u64 myH = mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
+#endif
                 const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
                 const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);  // big->small, small->big
                 if (ab == ba) {
@@ -439,6 +456,9 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             const Cls c = ev ? cB : cA;
             eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta, es, nullptr, nullptr, &guard);
         }
+#if MW_PROBE == 2   // (instruction-cost probe: a third evaluation whose sign is an opaque 0)
+        { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); eval_nodes<MAXT>(HA, Hp, cA, kA, tmax, z, lane, delta, es, nullptr, nullptr, &guard); }
+#endif
         fcm_lane_guard<MAXT>(delta, guard);
         O.myd = lane_in(4ull) ? es.d1 : O.myd;   // levels 1 and 2: node and arc counts of the two split graphs (scalars)
         if (MAXT >= 2) O.myd = lane_in(8ull) ? es.d2 : O.myd;
@@ -541,9 +561,8 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
     const u32 N = (u32)p.nprop;                            // <= FCM_LAUNCH_CHUNK per launch
     if (N == 0) return;
 
-    u64 *cntL = smem;
-    u64 *bminL = smem + 8, *bmaxL = smem + 16;
-    u32 *ctl = (u32 *)(smem + 24);                         // [0] head  [1] state inside the bounds?
+    u64 *ent = smem;                                       // E[i] = {count i, flag, bmin i, bmax i}; E[0]'s flag: state inside the bounds?
+    u32 *ctl = (u32 *)(smem + MW_HEAD_OFF);                // [0] head: the next proposal to decide
     u32 *ctx = (u32 *)(smem + MW_CTX_OFF);
     u32 *vis = (u32 *)(smem + MW_VIS_OFF);                 // [w]: every proposal of wave w below this index is in memory
     u32 *logL = (u32 *)(smem + MW_SHARED_WORDS);
@@ -569,11 +588,11 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         u64 *cnt_g = (u64 *)p.counts + (size_t)chain * FCM_DEV_MAX_COUNTS;
         const u64 c0 = cl ? cnt_g[lane] : 0ull;
         const u64 mn = cl ? p.bmin[lane] : 0ull, mx = cl ? p.bmax[lane] : ~0ull;   // zero-padded (src/util.rs:53-57)
-        if (lane < 8) { cntL[lane] = c0; bminL[lane] = mn; bmaxL[lane] = mx; }
-        if (lane < 16) vis[lane] = lane < (int)W ? (u32)lane : MW_NONE;
         const bool inb = ballot(cl && (c0 < mn || c0 > mx)) == 0ull;
+        if (lane < 9) { ent[lane * 4 + 0] = c0; ent[lane * 4 + 1] = (lane == 0 && inb) ? 1ull : 0ull; ent[lane * 4 + 2] = mn; ent[lane * 4 + 3] = mx; }   // (lane 8: 0, 0, 0, ~0)
+        if (lane < 16) vis[lane] = lane < (int)W ? (u32)lane : MW_NONE;
         if (lane == 0) {
-            ctl[0] = 0u; ctl[1] = inb ? 1u : 0u;
+            ctl[0] = 0u;
             *(u64 *)(ctx + MC_ROWS) = (u64)C.rows; *(u64 *)(ctx + MC_DBL) = (u64)C.dbl; *(u64 *)(ctx + MC_NB) = (u64)C.nb;
             *(u64 *)(ctx + MC_ETAB) = (u64)C.etab; *(u64 *)(ctx + MC_ROWS_BYTES) = C.rows_bytes; *(u64 *)(ctx + MC_SEED) = p.seed;
             *(u64 *)(ctx + MC_SAMPLED0) = st_g[0];         // Philox step index of proposal 0 of this launch
@@ -629,6 +648,9 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 
         // ---- in-order decision.  While waiting for the token, look at the decisions taken since `snap` as they are
         // published: by the time head == q only the last of them is left.
+        const u32 eoff = (u32)min(lane, 8) * 32u;                                 // this lane's count entry (lanes without one: entry 8)
+        const uint4 stat = *(const uint4 *)((const char *)ent + eoff + 16u);      // its bounds: they do not change, read outside the token
+        const u64 bmin = (u64)stat.x | ((u64)stat.y << 32), bmax = (u64)stat.z | ((u64)stat.w << 32);
         bool hit = O.need_exact != 0u;
         {
             const u32 cx0 = rdlane(sv, SR_CX0), cx1 = rdlane(sv, SR_CX1), dslot = rdlane(sv, SR_DSLOT);
@@ -680,21 +702,27 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // The commit's global stores are issued after the token is handed on: until this wave publishes them as
         // visible (vis, at its next proposal) every later proposal holds this decision against its reads anyway.
         MW_T(t_redo);
-        const bool l16 = lane < 8;
-        const u64 cnt = l16 ? cntL[lane] : 0ull, bmin = l16 ? bminL[lane] : 0ull, bmax = l16 ? bmaxL[lane] : ~0ull;
-        const u32 in_bounds = mw_uni(ctl[1]);
+        const uint4 dyn = *(const uint4 *)((const char *)ent + eoff);          // count (x, y), flag (z)
+        const u64 cnt = (u64)dyn.x | ((u64)dyn.y << 32);
+        const u32 in_bounds = rdlane(dyn.z, 0);
         const u32 flg = rdlane(sv, SR_FLAGS);
         const u32 nonempty = flg & SRF_NONEMPTY, is_dmove = (flg >> 1) & 1u;
         const u64 ncnt = cnt + (u64)(long long)O.myd;
         const u32 within = ballot(ncnt < bmin || ncnt > bmax) == 0ull ? 1u : 0u;
         const u32 commit = nonempty & within;
         MW_T(t_dec1);
-        if (commit && l16) cntL[lane] = ncnt;
-        if (lane < ML_WORDS) logL[(q & ring) * ML_WORDS + lane] = lane == 0 ? (commit | (is_dmove << 1)) : sv;
-        if (commit && !in_bounds && lane == 0) ctl[1] = 1u;
-        MW_T(t_dec2);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the log entry and the counts
-        __hip_atomic_store(&ctl[0], q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        {
+            const u32 ebase = mw_lds_addr(ent) + eoff;
+            if (commit) MW_LDS_ST64(ebase, ncnt, "0xff");
+            u32 lv = sv;                                                             // the log entry: the staged record under its header
+            asm("v_writelane_b32 %0, %1, 0" : "+v"(lv) : "s"(commit | (is_dmove << 1)));
+            const u32 laddr = mw_lds_addr(logL) + (q & ring) * (ML_WORDS * 4u) + (u32)lane * 4u;
+            MW_LDS_ST32(laddr, lv, "0xfff");
+            if (commit && !in_bounds) { const u32 one = 1u; MW_LDS_ST32(ebase + 8u, one, "1"); }
+            MW_T(t_dec2);
+            const u32 nh = q + 1u;
+            MW_LDS_ST32(mw_lds_addr(ctl), nh, "1");                                  // the token: after the entry and the counts, in order
+        }
         __builtin_amdgcn_s_setprio(0);
         if (commit) {
             // the commit's stores (one value twice if both changes fall into one word: double-edge move only)
@@ -733,7 +761,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         n_big += (flg >> 3) & 1u;
         if (nonempty) {
             if (ballot(O.myd < 0 && cnt < (u64)(-(long long)O.myd))) status |= 8u;  // reference assert, src/lib.rs:65
-            const u64 nz = ballot(l16 && ncnt != 0ull);                // flag_count never shrinks in length (src/lib.rs:72-74)
+            const u64 nz = ballot(lane < 8 && ncnt != 0ull);                // flag_count never shrinks in length (src/lib.rs:72-74)
             const u32 nlen = nz ? (u32)(64 - __clzll((long long)nz)) : 0u;
             if (nlen > count_len) count_len = nlen;
         }
@@ -745,7 +773,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
     if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&p.dbgbuf[(size_t)chain * 8 + i], (unsigned long long)st_acc[i]);
 #endif
     mw_barrier();   // every proposal decided
-    if (wv == 0 && lane < p.ncounts) ((u64 *)p.counts + (size_t)chain * FCM_DEV_MAX_COUNTS)[lane] = cntL[lane];
+    if (wv == 0 && lane < p.ncounts) ((u64 *)p.counts + (size_t)chain * FCM_DEV_MAX_COUNTS)[lane] = ent[lane * 4];
     if (lane == 0) {
         atomicAdd((unsigned long long *)&st_g[0], (unsigned long long)mine);
         atomicAdd((unsigned long long *)&st_g[1], (unsigned long long)accepted);

@@ -17,7 +17,7 @@ for ln, l in enumerate(src, 1):
     op = s.split()[0]
     if op.startswith('v_'):
         cur['valu'] += 1
-        if re.match(r'v_readlane_b32 s\d+, v6[0-9],', s) or re.match(r'v_writelane_b32 v6[0-9],', s): cur['spill'] += 1
+        if re.match(r'v_readlane_b32 s\d+, v\d+, \d+$', s) or re.match(r'v_writelane_b32 v\d+, s\d+, \d+$', s): cur['spill'] += 1   # immediate lane index: SGPR spill slots (and a few constant-lane reads of the code's own)
     elif op.startswith('s_'):
         cur['salu'] += 1
         if op.startswith('s_cbranch') or op == 's_branch': cur['tgt'].append(s.split()[-1])
