@@ -648,9 +648,6 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 
         // ---- in-order decision.  While waiting for the token, look at the decisions taken since `snap` as they are
         // published: by the time head == q only the last of them is left.
-        const u32 eoff = (u32)min(lane, 8) * 32u;                                 // this lane's count entry (lanes without one: entry 8)
-        const uint4 stat = *(const uint4 *)((const char *)ent + eoff + 16u);      // its bounds: they do not change, read outside the token
-        const u64 bmin = (u64)stat.x | ((u64)stat.y << 32), bmax = (u64)stat.z | ((u64)stat.w << 32);
         bool hit = O.need_exact != 0u;
         {
             const u32 cx0 = rdlane(sv, SR_CX0), cx1 = rdlane(sv, SR_CX1), dslot = rdlane(sv, SR_DSLOT);
@@ -702,27 +699,28 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // The commit's global stores are issued after the token is handed on: until this wave publishes them as
         // visible (vis, at its next proposal) every later proposal holds this decision against its reads anyway.
         MW_T(t_redo);
+        const u32 eoff = (u32)min(lane, 8) * 32u;                              // this lane's count entry (lanes without one: entry 8)
         const uint4 dyn = *(const uint4 *)((const char *)ent + eoff);          // count (x, y), flag (z)
+        const uint4 stat = *(const uint4 *)((const char *)ent + eoff + 16u);   // its bounds (the same round trip)
+        const u64 bmin = (u64)stat.x | ((u64)stat.y << 32), bmax = (u64)stat.z | ((u64)stat.w << 32);
         const u64 cnt = (u64)dyn.x | ((u64)dyn.y << 32);
         const u32 in_bounds = rdlane(dyn.z, 0);
         const u32 flg = rdlane(sv, SR_FLAGS);
         const u32 nonempty = flg & SRF_NONEMPTY, is_dmove = (flg >> 1) & 1u;
         const u64 ncnt = cnt + (u64)(long long)O.myd;
-        const u32 within = ballot(ncnt < bmin || ncnt > bmax) == 0ull ? 1u : 0u;
-        const u32 commit = nonempty & within;
+        const u64 outside = ballot(ncnt < bmin) | ballot(ncnt > bmax);         // (two compares into SGPR pairs and a scalar OR)
+        const u32 commit = outside == 0ull ? nonempty : 0u;
         MW_T(t_dec1);
-        {
-            const u32 ebase = mw_lds_addr(ent) + eoff;
-            if (commit) MW_LDS_ST64(ebase, ncnt, "0xff");
-            u32 lv = sv;                                                             // the log entry: the staged record under its header
-            asm("v_writelane_b32 %0, %1, 0" : "+v"(lv) : "s"(commit | (is_dmove << 1)));
-            const u32 laddr = mw_lds_addr(logL) + (q & ring) * (ML_WORDS * 4u) + (u32)lane * 4u;
-            MW_LDS_ST32(laddr, lv, "0xfff");
-            if (commit && !in_bounds) { const u32 one = 1u; MW_LDS_ST32(ebase + 8u, one, "1"); }
-            MW_T(t_dec2);
-            const u32 nh = q + 1u;
-            MW_LDS_ST32(mw_lds_addr(ctl), nh, "1");                                  // the token: after the entry and the counts, in order
-        }
+        const u32 ebase = mw_lds_addr(ent) + eoff;
+        if (commit) MW_LDS_ST64(ebase, ncnt, "0xff");
+        u32 lv = sv;                                                                 // the log entry: the staged record under its header
+        asm("v_writelane_b32 %0, %1, 0" : "+v"(lv) : "s"(commit | (is_dmove << 1)));
+        const u32 laddr = mw_lds_addr(logL) + (q & ring) * (ML_WORDS * 4u) + (u32)lane * 4u;
+        MW_LDS_ST32(laddr, lv, "0xfff");
+        if (commit && !in_bounds) { const u32 one = 1u; MW_LDS_ST32(ebase + 8u, one, "1"); }
+        MW_T(t_dec2);
+        const u32 nh = q + 1u;
+        MW_LDS_ST32(mw_lds_addr(ctl), nh, "1");                                      // the token: after the entry and the counts, in order
         __builtin_amdgcn_s_setprio(0);
         if (commit) {
             // the commit's stores (one value twice if both changes fall into one word: double-edge move only)
