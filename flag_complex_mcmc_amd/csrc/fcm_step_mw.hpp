@@ -12,16 +12,25 @@
 // is committed when it starts, and the decisions are then taken strictly in
 // order:
 //
-//   head (LDS)   number of proposals decided so far.  A wave notes head before
-//                its first read of mutable state (snap) and, when its counts
-//                are ready, waits until head == q: it then holds the token.
-//   log  (LDS)   ring of the last W decisions: accepted?, the pair(s) changed,
-//                the slot of the reciprocal list rewritten.
-//   token holder checks the log entries snap..q-1 against its own reads.  No
-//                hit (the rule, > 99 %): its counts are those of the exact
-//                sequential state; bounds check against the chain's counts (LDS),
-//                commit (read-modify-write of two bitmap words, the slot list),
-//                log entry, head = q+1 (release).  A hit, or a proposal that
+//   head (LDS)   number of proposals decided so far.  A wave whose counts are
+//                ready waits until head == q: it then holds the token.
+//   ring (LDS)   the records of the last 4W proposals: the pair(s) a proposal
+//                changes if accepted, the slot of the reciprocal list it
+//                rewrites -- published as soon as the proposal knows them
+//                (before its evaluations: "staged"), and marked accepted or
+//                dropped when it is decided.
+//   checks       a wave holds the records snap..q-1 against its own reads while
+//                it waits for the token, staged ones included: by the time the
+//                token arrives, nothing of that is left to do.  A conflict with
+//                a record that is only staged is looked at again when that
+//                proposal is decided (it may be dropped).  Under the token: one
+//                look at the state words of snap..q-1 (a proposal that was run
+//                again after being checked carries a mark: its record may have
+//                changed, it is checked again), then -- no hit, the rule,
+//                > 99 % -- the wave's counts are those of the exact sequential
+//                state: bounds check against the chain's counts (LDS), the
+//                record's state word, head = q+1, and after that the commit
+//                (two bitmap words, the slot list).  A hit, or a proposal that
 //                needs the wide evaluator or a long candidate search: run it
 //                again now -- every earlier commit is visible, nobody else can
 //                commit -- and decide on that (tallied as n_redo).
@@ -36,8 +45,10 @@
 // Visibility of those stores is tracked apart: wave w publishes vis[w] = "every proposal of mine below this index is
 // in memory" at the start of each proposal, after its own earlier stores have completed (s_waitcnt vmcnt(0), long
 // hidden behind the decision's tail).  snap = min over the waves of vis: every proposal below snap is visible to
-// whatever the wave loads from then on; the decisions snap..q-1 -- at most 2W-1 of them, the log keeps 2W -- are held
-// against its reads.  All waves of a workgroup run on one CU and share its vector L1: workgroup scope.
+// whatever the wave loads from then on; the proposals snap..q-1 -- at most 2W-1 of them -- are held against its reads.
+// A record's place in the ring is taken again 4W proposals later, by a proposal that starts after q+3W is decided: every
+// reader of it (up to q+2W-1) has been decided by then.  LDS executes a wave's operations in order: a record's state word is
+// written after its other words, head after the state word, with no wait in between.  All waves of a workgroup run on one CU and share its vector L1: workgroup scope.
 #pragma once
 #ifndef MW_PROBE
 #define MW_PROBE 0
@@ -57,14 +68,19 @@
 #ifndef MW_K_LANE
 #define MW_K_LANE 0
 #endif
+#ifndef MW_VEC_MIN
+#define MW_VEC_MIN 4u   // records to check from which the lookup maps pay (fewer: each is looked at exactly)
+#endif
 #ifndef MW_K_EVLOOP
 #define MW_K_EVLOOP 0
 #endif
 #define MW_NONE 0xFFFFFFFFu
-// log entry, u32 words: what a decision changed (flags = 0: nothing)
-enum { ML_FLAGS = 0, ML_BIG1, ML_SMALL1, ML_ID1, ML_BIG2, ML_SMALL2, ML_ID2, ML_DSLOT, ML_WCLR, ML_WSET, ML_WORDS = 12 };
-#define ML_ACCEPTED 1u
-#define ML_DMOVE 2u
+// state word of a record: (proposal index << 4) | flags | phase.  Phase 0: not there (not staged yet, or being
+// written again by its exact run); 1: staged -- what the proposal changes if it is accepted; 2: decided.
+#define MS_STAGED 1u
+#define MS_DECIDED 2u
+#define MS_ACCEPTED 4u
+#define MS_REDONE 8u    // decided on an exact run: the record may differ from what was staged
 
 // chain context, u32 words in LDS: what the out-of-line parts (table fill, exact run) need, so that the hot loop
 // does not have to keep it in registers
@@ -72,23 +88,30 @@ enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SE
        MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_XW = 28, MC_WORDS = 30 };
 
 // LDS map in u64 words:
-//   shared    E[9]: {count, inside-the-bounds flag (entry 0), bmin, bmax} | head | ctx[15] | vis[8] | log[2W][6]
+//   shared    E[9]: {count, inside-the-bounds flag (entry 0), bmin, bmax} | head | ctx[15] | vis[8] | ring[4W][7]
 //             (<= 8 count entries: tmax <= 6; entry 8 = {0, 0, 0, ~0} is what the lanes without a count read)
-//   per wave  Hp[64] | arc list[64] | draw table: 32 entries of 14 u32 [224]   (the entry of the proposal being run doubles as
-//             its staging record; the arc list as the exact run's per-lane results)
+//   per wave  Hp[64] | arc list[64] | draw table: 28 entries of 14 u32 [196]   (the arc list doubles as the exact run's
+//             per-lane results)
 //   wide evaluator (one: only the token holder runs it)
 #define MW_SHARED_WORDS 60u
 #define MW_HEAD_OFF 36u
 #define MW_CTX_OFF 37u
 #define MW_VIS_OFF 52u
 #define MW_TBL_WORDS 14u
-#define MW_WAVE_WORDS (128u + 16u * MW_TBL_WORDS)
+#ifndef MW_TBL_N
+#ifndef MW_TBL_N
+#define MW_TBL_N 28u
+#endif
+#endif
+#define MW_WAVE_WORDS (128u + (MW_TBL_N * MW_TBL_WORDS) / 2u)
+#define MW_REC_WORDS 14u                                  // a record: SR_* words, u32
+#define MW_RING_WORDS(W) (4u * (W) * (MW_REC_WORDS / 2u))   // u64 words
 __host__ __device__ constexpr inline unsigned fcm_mw_lds_words(int NW, int W)
 {
-    return MW_SHARED_WORDS + 12u * W + (unsigned)W * MW_WAVE_WORDS + fcm_lds_words(NW < 2 ? 2 : NW);
+    return MW_SHARED_WORDS + MW_RING_WORDS((unsigned)W) + (unsigned)W * MW_WAVE_WORDS + fcm_lds_words(NW < 2 ? 2 : NW);
 }
 // 4096 chains at W = 2 are all resident only if 16 workgroups fit the 160 KiB of a CU: 10 KiB each
-static_assert(fcm_mw_lds_words(2, 2) * 8u <= 10240u, "the W = 2 workgroup must stay within 10 KiB of LDS (16 per CU)");
+static_assert(MW_TBL_N != 28u || fcm_mw_lds_words(2, 2) * 8u <= 10240u, "the W = 2 workgroup must stay within 10 KiB of LDS (16 per CU)");
 
 __device__ __forceinline__ void mw_barrier()   // orders LDS only
 {
@@ -160,7 +183,7 @@ struct MwRec {
     u32 wid_clr, wid_set, bit_clr, bit_set, dslot, dnew, add_k;
     u32 id1, big1, small1, id2, big2, small2, cx0, cx1, sus;
 };
-enum { SR_FLAGS = 0, SR_BIG1, SR_SMALL1, SR_ID1, SR_BIG2, SR_SMALL2, SR_ID2, SR_DSLOT, SR_WCLR, SR_WSET, SR_CX0, SR_CX1, SR_SUS, SR_WORDS };
+enum { SR_FLAGS = 0, SR_BIG1, SR_SMALL1, SR_ID1, SR_BIG2, SR_SMALL2, SR_ID2, SR_DSLOT, SR_WCLR, SR_WSET, SR_CX0, SR_CX1, SR_SUS, SR_STATE, SR_WORDS };
 // SR_FLAGS: nonempty<<0 | dmove<<1 | used_wide<<2 | big_set<<3 | add_k<<8 (12 bits) | clr bit index<<20 | set bit index<<25
 #define SRF_NONEMPTY 1u
 #define SRF_DMOVE 2u
@@ -172,7 +195,8 @@ struct MwOut {
     u32 w_clr, w_set;       // per lane (all lanes alike): the two bitmap words the commit rewrites, as read beside the builds
     int myd;                // per lane: lane d holds the change of count[d] (32 bits: fcm_lane_guard / the wide evaluator's own check)
 };
-__device__ __forceinline__ void mw_stage(u32 *stage, const MwRec &R, int lane)
+// (the state word last: LDS takes the stores in order, a reader that finds the state finds the record)
+__device__ __forceinline__ void mw_stage(u32 *stage, const MwRec &R, int lane, u32 state)
 {
     if (lane == 0) {
         const u32 fl = R.nonempty | (R.is_dmove << 1) | (R.used_wide << 2) | (R.big_set << 3) | ((R.add_k & 0xFFFu) << 8)
@@ -180,7 +204,7 @@ __device__ __forceinline__ void mw_stage(u32 *stage, const MwRec &R, int lane)
         *(uint4 *)(stage + 0) = make_uint4(fl, R.big1, R.small1, R.id1);
         *(uint4 *)(stage + 4) = make_uint4(R.big2, R.small2, R.id2, R.dslot);
         *(uint4 *)(stage + 8) = make_uint4(R.wid_clr, R.wid_set, R.cx0, R.cx1);
-        stage[SR_SUS] = R.sus;
+        *(uint2 *)(stage + SR_SUS) = make_uint2(R.sus, state);
     }
     wave_sync();
 }
@@ -192,7 +216,7 @@ __device__ __forceinline__ void mw_stage(u32 *stage, const MwRec &R, int lane)
 // evaluator), on a state nobody else changes meanwhile.
 template <int MAXT, bool ROWS128, bool EXACT>
 __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds, int maxnw, u32 tv, u64 tt, u32 gchain, u64 seed, int lane, MwOut &O,
-                                       u32 *stage, u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u, u64 guard_limit = 0x7FFFFFFFull)
+                                       u32 *stage, u32 rec_q, u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u, u64 guard_limit = 0x7FFFFFFFull)
 {
     MwRec R;
     const int tmax = MAXT;
@@ -436,7 +460,9 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
         O.w_set = C.rows[R.wid_set];
     }
     R.dnew = R.id2;
-    mw_stage(stage, R, lane);   // the record, before the evaluations: nothing of it stays in registers across them
+    // the record, before the evaluations: nothing of it stays in registers across them, and the chain's other waves can
+    // hold it against their reads from now on (not if it is incomplete: they then wait for the exact run's)
+    mw_stage(stage, R, lane, (rec_q << 4) | ((EXACT || O.need_exact) ? 0u : MS_STAGED));
     if (nev) {
         int delta[MAXT + 1];
 #pragma unroll
@@ -489,12 +515,12 @@ __device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 t
     const u32 W = rdlane(cv, MC_W);
     const int maxnw = (int)rdlane(cv, MC_MAXNW);
     const MwChain C = mw_chain_from_lds(ctx, lane);
-    u64 *mine_lds = smem + MW_SHARED_WORDS + 12u * W + (size_t)wv * MW_WAVE_WORDS;
-    u64 *wide_lds = smem + MW_SHARED_WORDS + 12u * W + (size_t)W * MW_WAVE_WORDS;
+    u64 *mine_lds = smem + MW_SHARED_WORDS + MW_RING_WORDS(W) + (size_t)wv * MW_WAVE_WORDS;
+    u64 *wide_lds = smem + MW_SHARED_WORDS + MW_RING_WORDS(W) + (size_t)W * MW_WAVE_WORDS;
     const u64 seed = (u64)rdlane(cv, MC_SEED) | ((u64)rdlane(cv, MC_SEED + 1) << 32);
     const u64 sampled0 = (u64)rdlane(cv, MC_SAMPLED0) | ((u64)rdlane(cv, MC_SAMPLED0 + 1) << 32);
     MwOut O;
-    mw_run<MAXT, ROWS128, true>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, O, (u32 *)smem + stage_off, nullptr, 0u, 0u, 0u,
+    mw_run<MAXT, ROWS128, true>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, O, (u32 *)smem + stage_off, q, nullptr, 0u, 0u, 0u,
                                 (u64)rdlane(cv, MC_GUARD) | ((u64)rdlane(cv, MC_GUARD + 1) << 32));
     u32 *out = (u32 *)(mine_lds + 64);
     if (lane < 16) out[lane] = (u32)O.myd;
@@ -503,7 +529,109 @@ __device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 t
     wave_sync();
 }
 
-// ---- out of line: the wave's next 32 draws.  Lane j draws the wave's j-th proposal from q on ("Philox per lane"),
+// does the record `ev` (lane i = word i; not an empty transition), if accepted, change anything a proposal read?  The
+// proposal: its local vertex lists Lv1, Lv2 (per lane), the candidate pairs it looked at, the slot and the two bitmap
+// words it rewrites.
+__device__ __forceinline__ bool mw_touches(u32 ev, u32 Lv1, u32 Lv2, u32 cx0, u32 cx1, u32 dslot, u32 wid_clr, u32 wid_set)
+{
+    const u32 fl = rdlane(ev, SR_FLAGS);
+    const u32 b1 = rdlane(ev, SR_BIG1), s1 = rdlane(ev, SR_SMALL1), i1 = rdlane(ev, SR_ID1);
+    const u32 wc = rdlane(ev, SR_WCLR), ws = rdlane(ev, SR_WSET);
+    bool t = mw_inside(Lv1, b1, s1) || mw_inside(Lv2, b1, s1) || i1 == cx0 || i1 == cx1
+             || wc == wid_clr || wc == wid_set || ws == wid_clr || ws == wid_set;
+    if (fl & SRF_DMOVE) {
+        const u32 b2 = rdlane(ev, SR_BIG2), s2 = rdlane(ev, SR_SMALL2), i2 = rdlane(ev, SR_ID2);
+        t = t || mw_inside(Lv1, b2, s2) || mw_inside(Lv2, b2, s2) || i2 == cx0 || i2 == cx1 || rdlane(ev, SR_DSLOT) == dslot;
+    }
+    return t;
+}
+
+// ---- out of line: the wait for the token with several records to check (W >= 4).  All records snap..q-1 at once, one
+// per lane, and as soon as they are staged: by the time head == q nothing of that is left.  Whether a vertex is in one
+// of the proposal's local sets is looked up in two maps of 2048 bits (vertex id mod 2048: exact up to 2048 vertices,
+// a superset beyond), kept where the split graph was; a lane whose record looks like a conflict there is then looked
+// at exactly (mw_touches).  A conflict with a record that is only staged is looked at again when that proposal is
+// decided (it may be dropped).  Under the token: records checked as staged and then decided on an exact run may have
+// changed -- those are checked again.  Returns with the token held: 1 = the proposal has to be run again.
+__device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q, u32 snap, u32 Lv1, u32 Lv2, u32 hit0, u32 W, u32 sv)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    wv = mw_uni(wv); q = mw_uni(q); snap = mw_uni(snap);
+    bool hit = mw_uni(hit0) != 0u;
+    W = mw_uni(W);                                                        // (sv: the proposal's own record, lane i = word i)
+    const u32 ring = 4u * W - 1u;
+    const u32 *ringL = (const u32 *)(smem + MW_SHARED_WORDS);
+    const u32 *ctl = (const u32 *)(smem + MW_HEAD_OFF);
+    u64 *Hp = smem + MW_SHARED_WORDS + MW_RING_WORDS(W) + (size_t)wv * MW_WAVE_WORDS;
+    const u32 cx0 = rdlane(sv, SR_CX0), cx1 = rdlane(sv, SR_CX1), dslot = rdlane(sv, SR_DSLOT);
+    const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
+    auto touches = [&](u32 ev) -> bool { return (rdlane(ev, SR_FLAGS) & SRF_NONEMPTY) ? mw_touches(ev, Lv1, Lv2, cx0, cx1, dslot, wid_clr, wid_set) : false; };
+    const u32 nent = q - snap;                                            // 1 .. 2W - 1 <= 31
+    const u64 all = ~0ull >> (64u - nent);
+    u64 done = 0ull;                                                      // records that are no conflict (if only staged: as staged)
+    u32 *bmA = (u32 *)Hp, *bmB = bmA + 64;
+    if (!hit) {
+        Hp[lane] = 0ull;
+        if (Lv1 != MW_NONE) __hip_atomic_fetch_or(&bmA[(Lv1 >> 5) & 63u], 1u << (Lv1 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (Lv2 != MW_NONE) __hip_atomic_fetch_or(&bmB[(Lv2 >> 5) & 63u], 1u << (Lv2 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        wave_sync();
+    }
+    for (;;) {
+        const u32 h = mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // h <= q
+        if (!hit && done != all) {
+            const u32 pidx = snap + (u32)lane;
+            const u32 *e = ringL + (pidx & ring) * MW_REC_WORDS;          // (lanes >= nent read some record of the ring: masked below)
+            const u32 st = e[SR_STATE], fl = e[SR_FLAGS];
+            const u32 b1 = e[SR_BIG1], s1 = e[SR_SMALL1], i1 = e[SR_ID1], wc = e[SR_WCLR], ws = e[SR_WSET];
+            const u32 b2 = e[SR_BIG2], s2 = e[SR_SMALL2], i2 = e[SR_ID2], ds = e[SR_DSLOT];
+            auto in_map = [](const u32 *bm, u32 v) -> u32 { return (bm[(v >> 5) & 63u] >> (v & 31u)) & 1u; };
+            u32 cf = (in_map(bmA, b1) & in_map(bmA, s1)) | (in_map(bmB, b1) & in_map(bmB, s1));
+            cf |= (i1 == cx0 || i1 == cx1 || wc == wid_clr || wc == wid_set || ws == wid_clr || ws == wid_set) ? 1u : 0u;
+            u32 cf2 = (in_map(bmA, b2) & in_map(bmA, s2)) | (in_map(bmB, b2) & in_map(bmB, s2));
+            cf2 |= (i2 == cx0 || i2 == cx1 || ds == dslot) ? 1u : 0u;
+            cf |= (fl & SRF_DMOVE) ? cf2 : 0u;
+            cf &= fl;                                                     // SRF_NONEMPTY is bit 0: an empty transition changes nothing
+            const u64 there = ballot((st >> 4) == pidx && (st & 3u) != 0u) & all & ~done;
+            const u64 dropped = ballot((st & (MS_DECIDED | MS_ACCEPTED)) == MS_DECIDED);
+            const u64 maybe = ballot(cf != 0u);
+            done |= there & (dropped | ~maybe);
+            u64 look = there & maybe & ~dropped;
+            while (look && !hit) {
+                const u32 i = (u32)__ffsll((long long)look) - 1u;
+                look &= look - 1ull;
+                const u32 ev = lane < SR_WORDS ? ringL[((snap + i) & ring) * MW_REC_WORDS + lane] : 0u;
+                const u32 sti = rdlane(ev, SR_STATE);
+                if ((sti >> 4) != snap + i || (sti & 3u) == 0u) continue;           // being written again: later
+                if ((sti & (MS_DECIDED | MS_ACCEPTED)) == MS_DECIDED) { done |= 1ull << i; continue; }
+                if (!touches(ev)) done |= 1ull << i;
+                else if (sti & MS_DECIDED) hit = true;                              // (only staged: it may yet be dropped -- wait)
+            }
+        }
+        if (h == q) {
+            if (hit || done == all) break;
+            continue;                 // the token is here: the records that held the checks up are decided now
+        }
+        // not yet: doze by how far off the token is (a decision takes several hundred cycles)
+        const u32 dist = q - h;
+        if (dist >= 4u) __builtin_amdgcn_s_sleep(10);
+        else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
+        else __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
+    if (!hit) {
+        const u32 stw = lane < (int)nent ? ringL[((snap + (u32)lane) & ring) * MW_REC_WORDS + SR_STATE] : 0u;
+        u64 again = ballot((stw & (MS_REDONE | MS_ACCEPTED)) == (MS_REDONE | MS_ACCEPTED));
+        while (again && !hit) {
+            const u32 i = (u32)__ffsll((long long)again) - 1u;
+            again &= again - 1ull;
+            const u32 ev = lane < SR_WORDS ? ringL[((snap + i) & ring) * MW_REC_WORDS + lane] : 0u;
+            hit = touches(ev);
+        }
+    }
+    return hit ? 1u : 0u;
+}
+
+// ---- out of line: the wave's next MW_TBL_N draws.  Lane j draws the wave's j-th proposal from q on ("Philox per lane"),
 // with the static data it names.
 __device__ __attribute__((noinline)) void mw_fill_table(u64 *smem, u32 wv, u32 q)
 {
@@ -513,7 +641,7 @@ __device__ __attribute__((noinline)) void mw_fill_table(u64 *smem, u32 wv, u32 q
     const u32 cv = lane < MC_WORDS ? ctx[lane] : 0u;
     const u32 W = rdlane(cv, MC_W);
     const MwChain C = mw_chain_from_lds(ctx, lane);
-    u32 *T = (u32 *)(smem + MW_SHARED_WORDS + 12u * W + (size_t)wv * MW_WAVE_WORDS + 128);
+    u32 *T = (u32 *)(smem + MW_SHARED_WORDS + MW_RING_WORDS(W) + (size_t)wv * MW_WAVE_WORDS + 128);
     const u64 seed = (u64)rdlane(cv, MC_SEED) | ((u64)rdlane(cv, MC_SEED + 1) << 32);
     const u64 sampled0 = (u64)rdlane(cv, MC_SAMPLED0) | ((u64)rdlane(cv, MC_SAMPLED0 + 1) << 32);
     const u64 cum0 = (u64)rdlane(cv, MC_CUM0) | ((u64)rdlane(cv, MC_CUM0 + 1) << 32);
@@ -521,7 +649,7 @@ __device__ __attribute__((noinline)) void mw_fill_table(u64 *smem, u32 wv, u32 q
     const u64 cum2 = (u64)rdlane(cv, MC_CUM2) | ((u64)rdlane(cv, MC_CUM2 + 1) << 32);
     const u32 gchain = rdlane(cv, MC_GCHAIN), U = C.U, D = C.D;
     const u64 Mtot = (u64)U + D;
-    const int j = lane & 31;
+    const int j = lane < (int)MW_TBL_N ? lane : 0;
     const u64 tj = sampled0 + (u64)q + (u64)j * W;
     const u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
     u32 w[4];
@@ -541,7 +669,7 @@ __device__ __attribute__((noinline)) void mw_fill_table(u64 *smem, u32 wv, u32 q
         if (x0 < U) { c0 = (u32)x0; e = C.etab[x0]; }
         if (x1 < U) c1 = (u32)x1;
     }
-    if (lane < 32) {
+    if (lane < (int)MW_TBL_N) {
         u32 *t = T + j * MW_TBL_WORDS;
         t[0] = (u32)mv | ((w[1] & 1u) << 8); t[1] = ed; t[2] = (u32)ix; t[3] = (u32)(ix >> 32);
         t[4] = e.big; t[5] = e.small; t[6] = e.nb_off; t[7] = e.k;
@@ -565,12 +693,12 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
     u32 *ctl = (u32 *)(smem + MW_HEAD_OFF);                // [0] head: the next proposal to decide
     u32 *ctx = (u32 *)(smem + MW_CTX_OFF);
     u32 *vis = (u32 *)(smem + MW_VIS_OFF);                 // [w]: every proposal of wave w below this index is in memory
-    u32 *logL = (u32 *)(smem + MW_SHARED_WORDS);
-    const u32 ring = 2u * W - 1u;                          // log ring mask
+    u32 *ringL = (u32 *)(smem + MW_SHARED_WORDS);          // records of the last 4W proposals
+    const u32 ring = 4u * W - 1u;                          // ring mask
     const int maxnw = p.maxnw < 2 ? 2 : p.maxnw;
-    u64 *mine_lds = smem + MW_SHARED_WORDS + 12u * W + (size_t)wv * MW_WAVE_WORDS;
+    u64 *mine_lds = smem + MW_SHARED_WORDS + MW_RING_WORDS(W) + (size_t)wv * MW_WAVE_WORDS;
     u64 *Hp = mine_lds;                                    // split graph + arc list (eval_nodes / walk_nodes)
-    const u32 *T = (const u32 *)(mine_lds + 128);          // this wave's next 32 proposals
+    const u32 *T = (const u32 *)(mine_lds + 128);          // this wave's next MW_TBL_N proposals
     u64 *st_g = (u64 *)p.stats + (size_t)chain * FCM_DEV_NSTATS;
 
     const u64 guard_limit = MAXT >= 6 ? p.guard_limit : 0x7FFFFFFFull;
@@ -591,6 +719,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         const bool inb = ballot(cl && (c0 < mn || c0 > mx)) == 0ull;
         if (lane < 9) { ent[lane * 4 + 0] = c0; ent[lane * 4 + 1] = (lane == 0 && inb) ? 1ull : 0ull; ent[lane * 4 + 2] = mn; ent[lane * 4 + 3] = mx; }   // (lane 8: 0, 0, 0, ~0)
         if (lane < 16) vis[lane] = lane < (int)W ? (u32)lane : MW_NONE;
+        for (u32 i = (u32)lane; i <= ring; i += WAVE) ringL[i * MW_REC_WORDS + SR_STATE] = MW_NONE & ~15u;   // nobody's record
         if (lane == 0) {
             ctl[0] = 0u;
             *(u64 *)(ctx + MC_ROWS) = (u64)C.rows; *(u64 *)(ctx + MC_DBL) = (u64)C.dbl; *(u64 *)(ctx + MC_NB) = (u64)C.nb;
@@ -606,7 +735,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
     // this wave's share of the counters (added to the stats row at the end)
     u32 accepted = 0, n_empty = 0, n_dmove = 0, sum_k = 0, n_redo = 0, n_wide = 0, n_big = 0, mine = 0;
     u32 count_len = 0u, status = 0u;
-    u32 ti = 32u;                                          // next table entry; 32 = refill
+    u32 ti = MW_TBL_N;                                     // next table entry; MW_TBL_N = refill
 
 #ifdef MW_STAMP
     u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -623,7 +752,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 #if MW_K_LANE
         asm volatile("" : "+v"(lane));
 #endif
-        if (ti >= 32u) {
+        if (ti >= MW_TBL_N) {
             mw_fill_table(smem, wv, q);
             ti = 0u;
         }
@@ -636,9 +765,9 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // the oldest undecided proposal is what the chain's other waves end up waiting for: let it go first on its SIMD
         if (mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == q) __builtin_amdgcn_s_setprio(2);
         MwOut O;
-        u32 *stage = (u32 *)T + (ti - 1u) * MW_TBL_WORDS;   // the table entry just taken into `tv`: its place holds the staging record now
+        u32 *stage = ringL + (q & ring) * MW_REC_WORDS;      // this proposal's record
         MW_T(t_snap);
-        mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, O, stage, vis, wv, q, W, guard_limit);
+        mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, O, stage, q, vis, wv, q, W, guard_limit);
         const u32 snap = O.snap;
         MW_T(t_run);
 
@@ -646,28 +775,23 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         u32 sv = lane < SR_WORDS ? stage[lane] : 0u;
         u32 w_clr = O.w_clr, w_set = O.w_set;
 
-        // ---- in-order decision.  While waiting for the token, look at the decisions taken since `snap` as they are
-        // published: by the time head == q only the last of them is left.
+        // ---- in-order decision.  While waiting for the token, hold the records snap..q-1 against this proposal's reads.
         bool hit = O.need_exact != 0u;
-        {
+        const u32 nent = q - snap;                                            // <= 2W - 1
+        if (nent >= MW_VEC_MIN) {
+            // several records: all at once and as soon as they are staged (out of line, W >= 4)
+            hit = mw_wait_staged(smem, wv, q, snap, O.Lv1, O.Lv2, hit ? 1u : 0u, W, sv) != 0u;
+        } else {
+            // few records (W = 2 always): each is looked at once, when it is decided
             const u32 cx0 = rdlane(sv, SR_CX0), cx1 = rdlane(sv, SR_CX1), dslot = rdlane(sv, SR_DSLOT);
             const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
             u32 c = snap;
             for (;;) {
                 const u32 h = mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // h <= q
                 while (c < h && !hit) {
-                    const u32 ev = lane < ML_WORDS ? logL[(c & ring) * ML_WORDS + lane] : 0u;
+                    const u32 ev = lane < SR_WORDS ? ringL[(c & ring) * MW_REC_WORDS + lane] : 0u;
                     ++c;
-                    const u32 fl = rdlane(ev, ML_FLAGS);
-                    if (!(fl & ML_ACCEPTED)) continue;
-                    const u32 b1 = rdlane(ev, ML_BIG1), s1 = rdlane(ev, ML_SMALL1), i1 = rdlane(ev, ML_ID1);
-                    const u32 wc = rdlane(ev, ML_WCLR), ws = rdlane(ev, ML_WSET);
-                    hit = mw_inside(O.Lv1, b1, s1) || mw_inside(O.Lv2, b1, s1) || i1 == cx0 || i1 == cx1
-                          || wc == wid_clr || wc == wid_set || ws == wid_clr || ws == wid_set;
-                    if (fl & ML_DMOVE) {
-                        const u32 b2 = rdlane(ev, ML_BIG2), s2 = rdlane(ev, ML_SMALL2), i2 = rdlane(ev, ML_ID2);
-                        hit = hit || mw_inside(O.Lv1, b2, s2) || mw_inside(O.Lv2, b2, s2) || i2 == cx0 || i2 == cx1 || rdlane(ev, ML_DSLOT) == dslot;
-                    }
+                    if (rdlane(ev, SR_STATE) & MS_ACCEPTED) hit = mw_touches(ev, O.Lv1, O.Lv2, cx0, cx1, dslot, wid_clr, wid_set);   // (accepted: not empty)
                 }
                 if (h == q) break;
 #ifdef MW_STAMP
@@ -679,11 +803,12 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
                 else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
                 else __builtin_amdgcn_s_sleep(1);
             }
+            __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
         }
         MW_T(t_token);
-        __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
         if (hit) {
             // under the token nobody else can commit; once every earlier commit is in memory too, run it again, all of it
+            { const u32 gone = q << 4; MW_LDS_ST32(mw_lds_addr(stage + SR_STATE), gone, "1"); }   // the staged record is void from here on
             n_redo += 1u;
             while (mw_vis_min(vis, W, lane) < q) __builtin_amdgcn_s_sleep(1);
             mw_exact_call<MAXT, ROWS128>(smem, wv, tv, q, (u32)(stage - (u32 *)smem));
@@ -713,10 +838,8 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         MW_T(t_dec1);
         const u32 ebase = mw_lds_addr(ent) + eoff;
         if (commit) MW_LDS_ST64(ebase, ncnt, "0xff");
-        u32 lv = sv;                                                                 // the log entry: the staged record under its header
-        asm("v_writelane_b32 %0, %1, 0" : "+v"(lv) : "s"(commit | (is_dmove << 1)));
-        const u32 laddr = mw_lds_addr(logL) + (q & ring) * (ML_WORDS * 4u) + (u32)lane * 4u;
-        MW_LDS_ST32(laddr, lv, "0xfff");
+        const u32 fin = (q << 4) | (hit ? MS_REDONE : 0u) | (commit ? MS_ACCEPTED : 0u) | MS_DECIDED;   // the record's state word
+        MW_LDS_ST32(mw_lds_addr(stage + SR_STATE), fin, "1");
         if (commit && !in_bounds) { const u32 one = 1u; MW_LDS_ST32(ebase + 8u, one, "1"); }
         MW_T(t_dec2);
         const u32 nh = q + 1u;
