@@ -254,7 +254,7 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- parity gate on this rank's result (outside the timed region) ----------
-    keys = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big")
+    keys = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big", "n_recheck", "n_held")
     d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in keys}
     assert d["sampled"] == (hi - lo) * args.steps * args.proposals, "proposal count mismatch"
     assert (st1["status"] == 0).all(), "device-side consistency check failed"
@@ -296,7 +296,7 @@ def main():
             "mean_k": mean_k,
             "clique_move_fraction": float(d["n_cperm"] + d["n_cswap"]) / float(d["sampled"]),
             "changed_edges_per_clique_move": float(d["n_changes"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"])),
-            "rare_paths_per_1e6": {k: 1e6 * float(d[k]) / float(d["sampled"]) for k in ("n_redo", "n_wide", "n_big")},
+            "rare_paths_per_1e6": {k: 1e6 * float(d[k]) / float(d["sampled"]) for k in ("n_redo", "n_wide", "n_big", "n_recheck", "n_held")},
             "count_histogram_dim2_distinct": int(len(fdist.count_histogram(all_counts, 2)[0])),
             "parity": "counts == full GPU recount on 3 chains; oracle parity in tests/ -m gpu",
             "gathered_chains": int(all_counts.shape[0]),

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("FCM_LIB_PATH") or os.path.join(_HERE, "libfcm.so")
 MAX_COUNTS = 16
 NSTATS = 16
 STAT_NAMES = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "count_len", "status",
-              "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big", "reserved14", "reserved15")
+              "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big", "n_recheck", "n_held")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_PANIC, ERR_NOMEM, ERR_INTERNAL = range(9)
 

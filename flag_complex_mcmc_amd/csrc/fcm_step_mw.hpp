@@ -88,12 +88,13 @@ enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SE
        MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_XW = 28, MC_WORDS = 30 };
 
 // LDS map in u64 words:
-//   shared    E[9]: {count, inside-the-bounds flag (entry 0), bmin, bmax} | head | ctx[15] | vis[8] | ring[4W][7]
+//   shared    E[9]: {count, inside-the-bounds flag (entry 0), bmin, bmax} | head | ctx[15] | vis[8] | tallies[2 u32] | ring[4W][7]
 //             (<= 8 count entries: tmax <= 6; entry 8 = {0, 0, 0, ~0} is what the lanes without a count read)
 //   per wave  Hp[64] | arc list[64] | draw table: 28 entries of 14 u32 [196]   (the arc list doubles as the exact run's
 //             per-lane results)
 //   wide evaluator (one: only the token holder runs it)
-#define MW_SHARED_WORDS 60u
+#define MW_SHARED_WORDS 61u
+#define MW_TALLY_OFF 60u                                     // [0] proposals that checked a record again under the token, [1] that waited for a staged record's decision
 #define MW_HEAD_OFF 36u
 #define MW_CTX_OFF 37u
 #define MW_VIS_OFF 52u
@@ -563,6 +564,8 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
     const u32 *ringL = (const u32 *)(smem + MW_SHARED_WORDS);
     const u32 *ctl = (const u32 *)(smem + MW_HEAD_OFF);
     u64 *Hp = smem + MW_SHARED_WORDS + MW_RING_WORDS(W) + (size_t)wv * MW_WAVE_WORDS;
+    u32 *tally = (u32 *)(smem + MW_TALLY_OFF);
+    bool held = false;
     const u32 cx0 = rdlane(sv, SR_CX0), cx1 = rdlane(sv, SR_CX1), dslot = rdlane(sv, SR_DSLOT);
     const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
     auto touches = [&](u32 ev) -> bool { return (rdlane(ev, SR_FLAGS) & SRF_NONEMPTY) ? mw_touches(ev, Lv1, Lv2, cx0, cx1, dslot, wid_clr, wid_set) : false; };
@@ -604,7 +607,8 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
                 if ((sti >> 4) != snap + i || (sti & 3u) == 0u) continue;           // being written again: later
                 if ((sti & (MS_DECIDED | MS_ACCEPTED)) == MS_DECIDED) { done |= 1ull << i; continue; }
                 if (!touches(ev)) done |= 1ull << i;
-                else if (sti & MS_DECIDED) hit = true;                              // (only staged: it may yet be dropped -- wait)
+                else if (sti & MS_DECIDED) hit = true;
+                else held = true;                                                   // only staged: it may yet be dropped -- wait
             }
         }
         if (h == q) {
@@ -621,6 +625,7 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
     if (!hit) {
         const u32 stw = lane < (int)nent ? ringL[((snap + (u32)lane) & ring) * MW_REC_WORDS + SR_STATE] : 0u;
         u64 again = ballot((stw & (MS_REDONE | MS_ACCEPTED)) == (MS_REDONE | MS_ACCEPTED));
+        if (again && lane == 0) atomicAdd(&tally[0], 1u);
         while (again && !hit) {
             const u32 i = (u32)__ffsll((long long)again) - 1u;
             again &= again - 1ull;
@@ -628,6 +633,7 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
             hit = touches(ev);
         }
     }
+    if (held && lane == 0) atomicAdd(&tally[1], 1u);
     return hit ? 1u : 0u;
 }
 
@@ -722,6 +728,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         for (u32 i = (u32)lane; i <= ring; i += WAVE) ringL[i * MW_REC_WORDS + SR_STATE] = MW_NONE & ~15u;   // nobody's record
         if (lane == 0) {
             ctl[0] = 0u;
+            *(smem + MW_TALLY_OFF) = 0ull;
             *(u64 *)(ctx + MC_ROWS) = (u64)C.rows; *(u64 *)(ctx + MC_DBL) = (u64)C.dbl; *(u64 *)(ctx + MC_NB) = (u64)C.nb;
             *(u64 *)(ctx + MC_ETAB) = (u64)C.etab; *(u64 *)(ctx + MC_ROWS_BYTES) = C.rows_bytes; *(u64 *)(ctx + MC_SEED) = p.seed;
             *(u64 *)(ctx + MC_SAMPLED0) = st_g[0];         // Philox step index of proposal 0 of this launch
@@ -907,6 +914,11 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         if (n_redo) atomicAdd((unsigned long long *)&st_g[11], (unsigned long long)n_redo);
         if (n_wide) atomicAdd((unsigned long long *)&st_g[12], (unsigned long long)n_wide);
         if (n_big) atomicAdd((unsigned long long *)&st_g[13], (unsigned long long)n_big);
+        if (wv == 0) {
+            const u32 *tally = (const u32 *)(smem + MW_TALLY_OFF);
+            if (tally[0]) atomicAdd((unsigned long long *)&st_g[14], (unsigned long long)tally[0]);
+            if (tally[1]) atomicAdd((unsigned long long *)&st_g[15], (unsigned long long)tally[1]);
+        }
     }
 }
 

@@ -202,6 +202,8 @@ int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
                                  need the full candidate search / the wide evaluator); a timing diagnostic, not chain state */
 #define FCM_STAT_WIDE 12      /* proposals evaluated by the wide (multi-word, LDS) evaluator */
 #define FCM_STAT_BIG 13       /* evaluated local sets of more than 48 vertices (second trip of the whole-row build) */
+#define FCM_STAT_RECHECK 14   /* multi-wave kernel, W >= 4: proposals that had to check a record again under the token (it was decided on an exact run after they had checked it as staged) */
+#define FCM_STAT_HELD 15      /* multi-wave kernel, W >= 4: proposals that waited for the decision of a staged record in conflict with their reads */
 int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out);
 
 /* Directed edge list of one chain's current graph, ascending (from,to). */

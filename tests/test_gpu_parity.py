@@ -457,7 +457,7 @@ def test_save_state_load_state_resumes_exactly(fcm, oracle, tmp_path):
     for s in (a, b):
         assert (s.flag_counts() == straight.flag_counts()).all()
         for k, v in straight.stats().items():
-            if k != "n_redo":   # a timing diagnostic of the multi-wave kernel (proposals re-run under the token), not chain state
+            if k not in ("n_redo", "n_recheck", "n_held"):   # timing diagnostics of the multi-wave kernel (proposals re-run under the token), not chain state
                 assert (s.stats()[k] == v).all(), k
         for c in range(5):
             assert (s.edges(c) == straight.edges(c)).all()
@@ -670,7 +670,7 @@ def test_multi_wave_conflict_paths_trajectory_parity(fcm, oracle, monkeypatch, W
     run again under the token (n_redo), for every W."""
     from flag_complex_mcmc_amd import graphs
     monkeypatch.setenv("FCM_MW", str(W))
-    redo = 0
+    redo = recheck = held = 0
     for n, pr, gseed in ((12, 0.3, 5), (20, 0.3, 3), (9, 0.45, 7)):
         e = graphs.random_with_p(n, pr, seed=gseed)
         for w in ((0.5, 0.5, 0.0, 0.0), (0.0, 1.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0)):
@@ -678,7 +678,11 @@ def test_multi_wave_conflict_paths_trajectory_parity(fcm, oracle, monkeypatch, W
             assert s.info["waves_per_chain"] == W
             assert (s.stats()["status"] == 0).all()
             redo += int(s.stats()["n_redo"].sum())
+            recheck += int(s.stats()["n_recheck"].sum())
+            held += int(s.stats()["n_held"].sum())
     assert redo > 100
+    if W >= 4:   # the staged-record protocol: both of its rare paths ran (and the trajectories above are the oracle's)
+        assert recheck > 0 and held > 0, (recheck, held)
 
 
 @pytest.mark.parametrize("W", [2, 16])
