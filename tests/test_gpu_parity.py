@@ -652,6 +652,12 @@ def test_multi_wave_kernel_is_selected_and_switchable(fcm, monkeypatch):
     fc = g.flagser_count()
     b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.05))
     assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["waves_per_chain"] == 8         # few chains: many waves each
+    eb = graphs.random_with_p(1500, 0.02, seed=3)                                          # rows longer than a cache line: 16 up to 512 chains
+    gb = fcm.Graph.from_edges(1500, eb)
+    fcb = gb.flagser_count()
+    bb = fcm.Bounds.calculate(gb, fcb, fcm.Bounds.target(fcb, 0.05))
+    assert fcm.MCMCSampler(gb, bb, n_chains=2, seed=1).info["waves_per_chain"] == (16 if len(fcb) - 2 >= 2 else 1)
+    assert fcm.MCMCSampler(gb, bb, n_chains=513, seed=1).info["waves_per_chain"] == (8 if len(fcb) - 2 >= 2 else 1)
     assert fcm.MCMCSampler(g, b, n_chains=2048, seed=1).info["waves_per_chain"] == 4
     assert fcm.MCMCSampler(g, b, n_chains=1024, seed=1).info["waves_per_chain"] == 8
     assert fcm.MCMCSampler(g, b, n_chains=3000, seed=1).info["waves_per_chain"] == 2      # 3000 x 4 would not all be resident
