@@ -579,12 +579,17 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
         if (Lv2 != MW_NONE) __hip_atomic_fetch_or(&bmB[(Lv2 >> 5) & 63u], 1u << (Lv2 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         wave_sync();
     }
+    const u32 pidx = snap + (u32)lane;
+    const u32 *e = ringL + (pidx & ring) * MW_REC_WORDS;                  // this lane's record (lanes >= nent: some record of the ring, masked below)
+    const u32 a_head = mw_lds_addr(ctl), a_state = mw_lds_addr(e + SR_STATE);
+    u32 st;
     for (;;) {
-        const u32 h = mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // h <= q
+        // head, then the state words -- one round trip, in this order: with head == q every state word read is final
+        u32 hv;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(hv), "=&v"(st) : "v"(a_head), "v"(a_state) : "memory");
+        const u32 h = mw_uni(hv);                                         // h <= q
         if (!hit && done != all) {
-            const u32 pidx = snap + (u32)lane;
-            const u32 *e = ringL + (pidx & ring) * MW_REC_WORDS;          // (lanes >= nent read some record of the ring: masked below)
-            const u32 st = e[SR_STATE], fl = e[SR_FLAGS];
+            const u32 fl = e[SR_FLAGS];
             const u32 b1 = e[SR_BIG1], s1 = e[SR_SMALL1], i1 = e[SR_ID1], wc = e[SR_WCLR], ws = e[SR_WSET];
             const u32 b2 = e[SR_BIG2], s2 = e[SR_SMALL2], i2 = e[SR_ID2], ds = e[SR_DSLOT];
             auto in_map = [](const u32 *bm, u32 v) -> u32 { return (bm[(v >> 5) & 63u] >> (v & 31u)) & 1u; };
@@ -623,8 +628,8 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
     }
     __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
     if (!hit) {
-        const u32 stw = lane < (int)nent ? ringL[((snap + (u32)lane) & ring) * MW_REC_WORDS + SR_STATE] : 0u;
-        u64 again = ballot((stw & (MS_REDONE | MS_ACCEPTED)) == (MS_REDONE | MS_ACCEPTED));
+        // (st: read after head == q was -- final)
+        u64 again = ballot((st & (MS_REDONE | MS_ACCEPTED)) == (MS_REDONE | MS_ACCEPTED)) & all;
         if (again && lane == 0) atomicAdd(&tally[0], 1u);
         while (again && !hit) {
             const u32 i = (u32)__ffsll((long long)again) - 1u;
