@@ -90,8 +90,8 @@ enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SE
 // LDS map in u64 words:
 //   shared    E[9]: {count, inside-the-bounds flag (entry 0), bmin, bmax} | head | ctx[15] | vis[8] | tallies[2 u32] | ring[4W][7]
 //             (<= 8 count entries: tmax <= 6; entry 8 = {0, 0, 0, ~0} is what the lanes without a count read)
-//   per wave  Hp[64] | arc list[64] | draw table: 28 entries of 14 u32 [196]   (the arc list doubles as the exact run's
-//             per-lane results)
+//   per wave  Hp[64] | arc list[64] | draw table: 28 entries of 14 u32 [196] | tallies[9]   (the arc list doubles as the
+//             exact run's per-lane results; tallies: 17 u32, MA_*)
 //   wide evaluator (one: only the token holder runs it)
 #define MW_SHARED_WORDS 61u
 #define MW_TALLY_OFF 60u                                     // [0] proposals that checked a record again under the token, [1] that waited for a staged record's decision
@@ -104,7 +104,8 @@ enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SE
 #define MW_TBL_N 28u
 #endif
 #endif
-#define MW_WAVE_WORDS (128u + (MW_TBL_N * MW_TBL_WORDS) / 2u)
+#define MW_TALLY_WAVE_OFF (128u + (MW_TBL_N * MW_TBL_WORDS) / 2u)
+#define MW_WAVE_WORDS (MW_TALLY_WAVE_OFF + 9u)
 #define MW_REC_WORDS 14u                                  // a record: SR_* words, u32
 #define MW_RING_WORDS(W) (4u * (W) * (MW_REC_WORDS / 2u))   // u64 words
 __host__ __device__ constexpr inline unsigned fcm_mw_lds_words(int NW, int W)
@@ -129,6 +130,12 @@ __device__ __forceinline__ u64 mw_build(const rsrc_t rr, u32 stride32, u32 Lv, i
     if constexpr (ROWS128) return build_local_rows128(rr, Lv, s, lane);
     else return build_local_loop16(rr, stride32, Lv, s, lane);
 }
+
+// The wave's tallies, u32 words in LDS (added to the chain's stats row at the end): counters (the first four are the low
+// bits of the staged flags word), then one flag per count entry -- was it ever non-zero after a transition (flag_count
+// never shrinks in length, src/lib.rs:72-74) -- and the OR of the proposals' status words.  In LDS rather than in a
+// dozen scalars that would live, spilled, across the whole loop.
+enum { MA_NONEMPTY = 0, MA_DMOVE = 1, MA_WIDE = 2, MA_BIG = 3, MA_MINE = 4, MA_ACCEPTED = 5, MA_REDO = 6, MA_SUMK = 7, MA_NZ0 = 8, MA_STATUS = 16, MA_WORDS = 17 };
 
 // both endpoints of the pair (big, small) in the local list Lv?  (lanes beyond the list repeat its last vertex)
 __device__ __forceinline__ bool mw_inside(u32 Lv, u32 big, u32 small) { return ballot(Lv == big) != 0ull && ballot(Lv == small) != 0ull; }
@@ -745,8 +752,9 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
     mw_barrier();
 
     // this wave's share of the counters (added to the stats row at the end)
-    u32 accepted = 0, n_empty = 0, n_dmove = 0, sum_k = 0, n_redo = 0, n_wide = 0, n_big = 0, mine = 0;
-    u32 count_len = 0u, status = 0u;
+    u32 *tly = (u32 *)(mine_lds + MW_TALLY_WAVE_OFF);       // MA_* words
+    if (lane < MA_WORDS + 1) tly[lane] = 0u;
+    wave_sync();
     u32 ti = MW_TBL_N;                                     // next table entry; MW_TBL_N = refill
 
 #ifdef MW_STAMP
@@ -770,7 +778,6 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         }
         const u32 tv = lane < (int)MW_TBL_WORDS ? T[ti * MW_TBL_WORDS + lane] : 0u;
         ++ti;
-        if ((rdlane(tv, 0) & 0xFFu) >= 2u) status |= 4u;   // this kernel has no clique moves
 
         // ---- the proposal on the state as committed now.  Commits below snap are visible to every load from here on;
         // those from snap on are held against this proposal's reads before it is decided.
@@ -821,7 +828,6 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         if (hit) {
             // under the token nobody else can commit; once every earlier commit is in memory too, run it again, all of it
             { const u32 gone = q << 4; MW_LDS_ST32(mw_lds_addr(stage + SR_STATE), gone, "1"); }   // the staged record is void from here on
-            n_redo += 1u;
             while (mw_vis_min(vis, W, lane) < q) __builtin_amdgcn_s_sleep(1);
             mw_exact_call<MAXT, ROWS128>(smem, wv, tv, q, (u32)(stage - (u32 *)smem));
             const u32 *out = (const u32 *)(mine_lds + 64);
@@ -883,20 +889,21 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         }
 #endif
 
-        // ---- the token is gone: this wave's counters (sampled += 1, src/lib.rs:185)
-        status |= rdlane(sv, SR_SUS);
-        mine += 1u;
-        accepted += commit | ((nonempty ^ 1u) & in_bounds);   // an empty transition is accepted iff the state is inside the bounds
-        n_empty += nonempty ^ 1u;
-        n_dmove += nonempty & is_dmove;
-        sum_k += (flg >> 8) & 0xFFFu;
-        n_wide += (flg >> 2) & 1u;
-        n_big += (flg >> 3) & 1u;
-        if (nonempty) {
-            if (ballot(O.myd < 0 && cnt < (u64)(-(long long)O.myd))) status |= 8u;  // reference assert, src/lib.rs:65
-            const u64 nz = ballot(lane < 8 && ncnt != 0ull);                // flag_count never shrinks in length (src/lib.rs:72-74)
-            const u32 nlen = nz ? (u32)(64 - __clzll((long long)nz)) : 0u;
-            if (nlen > count_len) count_len = nlen;
+        // ---- the token is gone: this wave's tallies (sampled += 1, src/lib.rs:185).  Lanes 0..7 add to the counters --
+        // the low four flag bits are the lanes of their counters as they stand -- lanes 0..8 OR into the flags.
+        {
+            const u32 acc_inc = commit | ((nonempty ^ 1u) & in_bounds);       // an empty transition is accepted iff the state is inside the bounds
+            const u64 im = (u64)((flg & 0xFu) | (1u << MA_MINE) | (acc_inc << MA_ACCEPTED) | ((hit ? 1u : 0u) << MA_REDO));
+            u32 inc = lane_in(im) ? 1u : 0u;
+            inc = lane_in(1ull << MA_SUMK) ? ((flg >> 8) & 0xFFFu) : inc;
+            // a count never goes below zero (reference assert, src/lib.rs:65; counts stay far below 2^63, so a negative sum is that)
+            const u32 below = (nonempty && (ballot((int)(u32)(ncnt >> 32) < 0) & 0xFFull)) ? 8u : 0u;
+            const u32 stw = rdlane(sv, SR_SUS) | below | ((rdlane(tv, 0) & 0xFEu) ? 4u : 0u);   // (move >= 2: this kernel has no clique moves)
+            u32 orv = (nonempty && ncnt != 0ull) ? 1u : 0u;                   // lanes 0..7: count entry non-zero after this transition
+            orv = lane_in(1ull << 8) ? stw : orv;
+            const u32 taddr = mw_lds_addr(tly) + (u32)lane * 4u;
+            asm volatile("s_mov_b64 exec, 0xff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0x1ff\n\tds_or_b32 %0, %2 offset:32\n\ts_mov_b64 exec, -1"
+                         :: "v"(taddr), "v"(inc), "v"(orv) : "memory");
         }
     }
 
@@ -907,13 +914,18 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 #endif
     mw_barrier();   // every proposal decided
     if (wv == 0 && lane < p.ncounts) ((u64 *)p.counts + (size_t)chain * FCM_DEV_MAX_COUNTS)[lane] = ent[lane * 4];
+    const u32 tl = lane < MA_WORDS ? tly[lane] : 0u;
+    const u64 nzm = ballot(tl != 0u) >> MA_NZ0 & 0xFFull;
+    const u32 count_len = nzm ? (u32)(64 - __clzll((long long)nzm)) : 0u;
+    const u32 mine = rdlane(tl, MA_MINE), n_nonempty = rdlane(tl, MA_NONEMPTY), n_dmove = rdlane(tl, MA_DMOVE);
+    const u32 n_redo = rdlane(tl, MA_REDO), n_wide = rdlane(tl, MA_WIDE), n_big = rdlane(tl, MA_BIG), status = rdlane(tl, MA_STATUS);
     if (lane == 0) {
         atomicAdd((unsigned long long *)&st_g[0], (unsigned long long)mine);
-        atomicAdd((unsigned long long *)&st_g[1], (unsigned long long)accepted);
-        atomicAdd((unsigned long long *)&st_g[2], (unsigned long long)n_empty);
-        atomicAdd((unsigned long long *)&st_g[3], (unsigned long long)(mine - n_empty - n_dmove));
+        atomicAdd((unsigned long long *)&st_g[1], (unsigned long long)rdlane(tl, MA_ACCEPTED));
+        atomicAdd((unsigned long long *)&st_g[2], (unsigned long long)(mine - n_nonempty));
+        atomicAdd((unsigned long long *)&st_g[3], (unsigned long long)(n_nonempty - n_dmove));
         atomicAdd((unsigned long long *)&st_g[4], (unsigned long long)n_dmove);
-        atomicAdd((unsigned long long *)&st_g[5], (unsigned long long)sum_k);
+        atomicAdd((unsigned long long *)&st_g[5], (unsigned long long)rdlane(tl, MA_SUMK));
         atomicMax((unsigned long long *)&st_g[6], (unsigned long long)count_len);
         if (status) atomicOr((unsigned long long *)&st_g[7], (unsigned long long)status);
         if (n_redo) atomicAdd((unsigned long long *)&st_g[11], (unsigned long long)n_redo);
