@@ -84,7 +84,7 @@ def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
             "single_thread_proposals_per_s": 1.0 / per_prop}
 
 
-def load_traffic(config, n_chains, proposals):
+def load_traffic(config, n_chains, proposals, moves="simple"):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC summary of this same command
     (profiles/pmc_summary.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE
     passes), or (None, None).  A replay of a profiled run, not a measurement of this one: the source says so."""
@@ -92,7 +92,7 @@ def load_traffic(config, n_chains, proposals):
     try:
         recs = json.load(open(path))
         for rec in (recs if isinstance(recs, list) else [recs]):
-            if rec.get("config", 2) == config and rec.get("n_chains") == n_chains and rec.get("proposals") == proposals:
+            if rec.get("config", 2) == config and rec.get("n_chains") == n_chains and rec.get("proposals") == proposals and rec.get("moves", "simple") == moves:
                 return rec.get("hbm_bytes_per_launch"), "replayed from profiles/pmc_summary.json (%s): rocprofv3 --pmc passes of this command, not this run" % rec.get("tag", "?")
     except Exception:
         pass
@@ -279,7 +279,7 @@ def main():
         long_rows = n > 1024
         abytes = needed_bytes(d, n, mean_k) / args.steps if long_rows else survey_bytes
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals) if args.moves == "simple" else (None, None)
+        traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals, args.moves)
         out = {
             "metric": METRIC, "value": total_prop / elapsed, "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

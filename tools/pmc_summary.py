@@ -22,13 +22,14 @@ cw = counters("calib_WRITE_SIZE", "calib_kernel", "WRITE_SIZE")
 fetch_corr = calib_read_bytes / (sum(cf) / len(cf) * 1024.0)
 write_bytes_per_store = (sum(cw[3:]) / len(cw[3:]) * 1024.0) / calib_write_stores
 out = []
-for k in (1, 2, 3, 4):
-    sf, sw = counters("c%d_FETCH_SIZE" % k, "fcm_step_", "FETCH_SIZE"), counters("c%d_WRITE_SIZE" % k, "fcm_step_", "WRITE_SIZE")
-    if not sf or not sw or not os.path.exists("%s/c%d_FETCH_SIZE.json" % (d, k)):
+for key in ("1", "2", "3", "4", "d2"):       # d2: the default move mix on config 2
+    k, moves = int(key[-1]), ("default" if key.startswith("d") else "simple")
+    sf, sw = counters("c%s_FETCH_SIZE" % key, "fcm_step_", "FETCH_SIZE"), counters("c%s_WRITE_SIZE" % key, "fcm_step_", "WRITE_SIZE")
+    if not sf or not sw or not os.path.exists("%s/c%s_FETCH_SIZE.json" % (d, key)):
         continue
-    bench = json.load(open("%s/c%d_FETCH_SIZE.json" % (d, k)))
+    bench = json.load(open("%s/c%s_FETCH_SIZE.json" % (d, key)))
     # the first launches are warm-up; all launches run the same number of proposals
-    rec = {"tag": tag, "config": k, "n_chains": bench["config"]["chains_per_gpu"], "proposals": bench["config"]["proposals_per_step"],
+    rec = {"tag": tag, "config": k, "moves": moves, "n_chains": bench["config"]["chains_per_gpu"], "proposals": bench["config"]["proposals_per_step"],
            "kernel": bench["roofline"]["kernel"], "waves_per_chain": bench["roofline"]["waves_per_chain"],
            "launches_seen": len(sf), "FETCH_SIZE_KB_per_launch": sum(sf) / len(sf), "WRITE_SIZE_KB_per_launch": sum(sw) / len(sw),
            "fetch_correction": fetch_corr, "calib_write_bytes_per_dword_store": write_bytes_per_store,

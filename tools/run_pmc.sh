@@ -15,5 +15,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   for K in $CONFIGS; do
     timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/c${K}_$C -- python3 $ROOT/bench.py --config $K --steps 2 --warmup 1 --no-cpu-baseline > $OUT/c${K}_$C.json 2> $OUT/c${K}_$C.err || echo "config $K $C failed"
   done
+  # the default move mix (clique moves, one-wave kernel) on the headline config
+  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/cd2_$C -- python3 $ROOT/bench.py --config 2 --moves default --steps 2 --warmup 1 --no-cpu-baseline > $OUT/cd2_$C.json 2> $OUT/cd2_$C.err || echo "default mix $C failed"
 done
 echo done
