@@ -24,7 +24,7 @@ cnt = tot[5]
 raw = out[:, 6].astype(np.uint64)
 d1 = float((raw & np.uint64(0xFFFFFFFF)).sum()) / cnt
 d2 = float((raw >> np.uint64(32)).sum()) / cnt
-print("config %d, %d chains, W=%d: %d proposals, %.1f polls per proposal; decision = %.0f (counts, bounds) + %.0f (stores) + rest (log, head)" % (cfg, chains, s.info["waves_per_chain"], cnt, tot[7] / cnt, d1, d2))
+print("config %d, %d chains, W=%d: %d proposals, %.1f polls per proposal; decision = %.0f (counts, bounds) + %.0f (stores) + rest (state word, head)" % (cfg, chains, s.info["waves_per_chain"], cnt, tot[7] / cnt, d1, d2))
 for i, nm in enumerate(names):
     print("  %-50s %9.0f cycles per proposal" % (nm, tot[i] / cnt))
 print("  %-50s %9.0f" % ("sum (per wave per proposal)", tot[:5].sum() / cnt))
