@@ -71,6 +71,9 @@
 #ifndef MW_VEC_MIN
 #define MW_VEC_MIN 4u   // records to check from which the lookup maps pay (fewer: each is looked at exactly)
 #endif
+#ifndef MW_SLEEP_NEAR
+#define MW_SLEEP_NEAR 12  // s_sleep argument (x 64 cycles) between polls when the token is one decision away, few-records path
+#endif
 #ifndef MW_K_EVLOOP
 #define MW_K_EVLOOP 0
 #endif
@@ -820,7 +823,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
                 const u32 dist = q - h;
                 if (dist >= 4u) __builtin_amdgcn_s_sleep(10);
                 else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
-                else __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(MW_SLEEP_NEAR);
             }
             __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
         }
