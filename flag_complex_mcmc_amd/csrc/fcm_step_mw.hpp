@@ -211,7 +211,7 @@ __device__ __forceinline__ void mw_stage(u32 *stage, const MwRec &R, int lane, u
 {
     if (lane == 0) {
         const u32 fl = R.nonempty | (R.is_dmove << 1) | (R.used_wide << 2) | (R.big_set << 3) | ((R.add_k & 0xFFFu) << 8)
-                       | ((u32)(R.bit_clr ? __ffs((int)R.bit_clr) - 1 : 0) << 20) | ((u32)(R.bit_set ? __ffs((int)R.bit_set) - 1 : 0) << 25);
+                       | (R.bit_clr << 20) | (R.bit_set << 25);   // (bit indices, 0..31)
         *(uint4 *)(stage + 0) = make_uint4(fl, R.big1, R.small1, R.id1);
         *(uint4 *)(stage + 4) = make_uint4(R.big2, R.small2, R.id2, R.dslot);
         *(uint4 *)(stage + 8) = make_uint4(R.wid_clr, R.wid_set, R.cx0, R.cx1);
@@ -254,7 +254,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     const int move = (int)(rdlane(tv, 0) & 0xFFu);
     const u32 coin = (rdlane(tv, 0) >> 8) & 1u;
     const u64 idx = (u64)rdlane(tv, 2) | ((u64)rdlane(tv, 3) << 32);
-    const u32 U = C.U, stride32 = C.stride32;
+    const u32 U = C.U, stride32 = ROWS128 ? 32u : C.stride32;   // (cache-line rows: a constant, word ids by shifts)
     const u64 Mtot = (u64)U + C.D;
     const rsrc_t rr = make_rows_rsrc(C.rows, C.rows_bytes);
 
@@ -327,8 +327,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             if (fres > 0 && !O.need_exact) {
                 R.nonempty = 1u;
                 const u32 cf = fres == 1 ? e1.big : e1.small, ct = fres == 1 ? e1.small : e1.big;
-                R.wid_clr = fres == 1 ? wid_bs : wid_sb; R.bit_clr = 1u << (ct & 31u);
-                R.wid_set = fres == 1 ? wid_sb : wid_bs; R.bit_set = 1u << (cf & 31u);
+                R.wid_clr = fres == 1 ? wid_bs : wid_sb; R.bit_clr = ct & 31u;
+                R.wid_set = fres == 1 ? wid_sb : wid_bs; R.bit_set = cf & 31u;
                 R.add_k = (u32)k; R.big_set = k + 2 > 48 ? 1u : 0u;
             }
         }
@@ -457,8 +457,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             }
             if (!okd) R.sus |= 2u;  // slot list says reciprocal, bitmap says not
             R.nonempty = 1u; R.is_dmove = 1u;
-            R.wid_clr = dfrom * stride32 + (dto >> 5); R.bit_clr = 1u << (dto & 31u);
-            R.wid_set = eb * stride32 + (ea >> 5); R.bit_set = 1u << (ea & 31u);
+            R.wid_clr = dfrom * stride32 + (dto >> 5); R.bit_clr = dto & 31u;
+            R.wid_set = eb * stride32 + (ea >> 5); R.bit_set = ea & 31u;
             R.dnew = (u32)cand;
             R.add_k = (u32)(dk + rk); R.big_set = (dk + 2 > 48 || rk + 2 > 48) ? 1u : 0u;
         }
@@ -466,9 +466,9 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     snap_point();   // (paths without a load of mutable state)
     // the two bitmap words a commit rewrites, read here -- lines the builds have just touched -- so that the commit is
     // two plain stores.  Issued last: the round trip runs beside the wait for the token instead of in front of it.
-    if (R.nonempty) {
-        O.w_clr = C.rows[R.wid_clr];
-        O.w_set = C.rows[R.wid_set];
+    if (R.nonempty) {   // (through the descriptor: the word id goes into the scalar offset, no 64-bit address arithmetic)
+        O.w_clr = __builtin_amdgcn_raw_buffer_load_b32(rr, 0, (int)(R.wid_clr * 4u), 0);
+        O.w_set = __builtin_amdgcn_raw_buffer_load_b32(rr, 0, (int)(R.wid_set * 4u), 0);
     }
     R.dnew = R.id2;
     // the record, before the evaluations: nothing of it stays in registers across them, and the chain's other waves can
