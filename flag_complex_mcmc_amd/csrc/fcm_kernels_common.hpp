@@ -188,14 +188,25 @@ __device__ __forceinline__ void build_issue(const rsrc_t rsrc, u32 voff, u32 rof
             w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, I0 + q), 0);
     }
 }
+// h |= (bit bpos of x) << POS: v_bfe, v_lshl_or (written out: hipcc would make it v_bfe, v_lshl and half a v_or3)
+template <int POS>
+__device__ __forceinline__ void build_put(u32 &h, u32 x, u32 bpos)
+{
+    const u32 b = __builtin_amdgcn_ubfe(x, bpos, 1u);
+    asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(h) : "v"(b), "n"(POS));
+}
+template <int Q, int N>
+__device__ __forceinline__ void build_put_all(u32 &h, const u32 (&w)[N], u32 bpos)
+{
+    if constexpr (Q < N) { build_put<Q>(h, w[Q], bpos); build_put_all<Q + 1, N>(h, w, bpos); }
+}
 // ... and keep this lane's bit of each: bit I0+q of the mask.  A slot that was not read holds 0.
 template <int I0, int N, int Q = 0>
 __device__ __forceinline__ void build_consume(const u32 (&w)[N], u32 bpos, u32 &hlo, u32 &hhi)
 {
     if constexpr (Q < N) {
         constexpr int R = I0 + Q;
-        const u32 bit = __builtin_amdgcn_ubfe(w[Q], bpos, 1u);
-        if constexpr (R < 32) hlo |= bit << R; else hhi |= bit << (R - 32);
+        if constexpr (R < 32) build_put<R>(hlo, w[Q], bpos); else build_put<R - 32>(hhi, w[Q], bpos);
         build_consume<I0, N, Q + 1>(w, bpos, hlo, hhi);
     }
 }
@@ -276,8 +287,7 @@ __device__ __forceinline__ u64 build_local_loop16(const rsrc_t rsrc, u32 stride3
             if (i0 + q < s) w[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rdlane(roff, i0 + q), 0);
         }
         u32 part = 0u;   // bits i0 .. i0+15 of the mask, at positions 0..15
-#pragma unroll
-        for (int q = 0; q < 16; ++q) part |= __builtin_amdgcn_ubfe(w[q], bpos, 1u) << q;
+        build_put_all<0, 16>(part, w, bpos);
         if (i0 < 32) hlo |= part << i0; else hhi |= part << (i0 - 32);
     }
     return act ? ((u64)hlo | ((u64)hhi << 32)) : 0ull;
@@ -304,13 +314,6 @@ __device__ __forceinline__ void build128_issue(const rsrc_t rsrc, u32 Lv, u32 se
             build128_issue<G + 1, G0, G1, NW>(rsrc, Lv, sel, dw, s, w);
         }
     }
-}
-// h |= (bit bpos of x) << POS: v_bfe, v_lshl_or (written out: hipcc would make it v_bfe, v_lshl and half a v_or3)
-template <int POS>
-__device__ __forceinline__ void build_put(u32 &h, u32 x, u32 bpos)
-{
-    const u32 b = __builtin_amdgcn_ubfe(x, bpos, 1u);
-    asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(h) : "v"(b), "n"(POS));
 }
 // ... and consume
 template <int Q, int Q0, int NW>
