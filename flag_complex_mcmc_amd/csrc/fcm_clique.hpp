@@ -91,17 +91,18 @@ struct CliqueResult {
     u64 sum_k;
     long long wide_d; // this lane's share of deltas that came through the wide path
     u32 status;
+    u32 n_wide;       // pairs of this move that took a multi-word evaluator
 };
 
 // Builds the changed-pair list of a clique move and applies it to the bitmap,
 // adding the simplex-count change to `delta` (fast evaluations) and res.wide_d
 // (wide).  move == 2: clique_permute, 3: clique_swap.
-template <int MAXT>
+template <int MAXT, bool XW>
 __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, const rsrc_t rrows, u64 *smem, const CliqueLds CL, int move,
                                                        u32 w1, u64 x64, u64 step, u32 gchain, u32 k0, u32 k1, int lane, int tmax,
                                                        int maxnw, int (&delta)[MAXT + 1], EvScal &es, u64 *sacc, u64 *stt, FcmGuard *guard = nullptr)
 {
-    CliqueResult res = {0, 0, 0ull, 0ll, 0u};
+    CliqueResult res = {0, 0, 0ull, 0ll, 0u, 0u};
     u64 *Hp = smem + WAVE;
     const u32 stride32 = p.stride32;
     // ---- clique_order_distribution.sample, cliques.choose (src/lib.rs:215-216, 235-237)
@@ -302,8 +303,37 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
             }
             CLQ_STAMP(5);                                              // per pair: evaluations + stores
         }
+        // (XW: kernel variants 6_2 / 14_2, chosen when the graph has such a pair: inlined into every clique kernel this rare
+        //  path costs 3 % in allocation quality, as a call 9 %)
+        if constexpr (XW) if (!done && s > 64 * maxnw) {
+            // 257 .. 1024 local vertices (a hub pair): the evaluator with its masks in the chain's HBM workspace (fcm_xwide.hpp)
+            u64 *xw = p.xw_ws ? (u64 *)p.xw_ws + (size_t)blockIdx.x * FCM_XW_WORDS : nullptr;
+            if (!xw || s > 64 * FCM_XW_MAXNW) { res.status |= 1u; continue; }
+            res.n_wide += 1u;
+            bool first = true;
+            for (int dir = 0; dir < 2; ++dir) {
+                if (!(dir == 0 ? need_bs : need_sb)) continue;
+                const bool add = (dir == 0 ? n_bs : n_sb) != 0u;
+                u32 *word = dir == 0 ? wbs : wsb;
+                const u32 bit = dir == 0 ? bit_s : bit_b;
+                if (add) {
+                    if (lane == 0) *word |= bit;
+                    wave_sync();
+                }
+                if (!xw_edge(xw, rows, stride32, p.nb, off, k, big, small, dir == 0 ? 1u : 0u, add ? +1 : -1, lane, tmax, !first)) res.status |= 1u;
+                first = false;
+                if (!add) {
+                    if (lane == 0) *word &= ~bit;
+                    wave_sync();
+                }
+            }
+            if (lane >= 2 && lane < 16 && lane - 1 <= tmax) res.wide_d += xw_count(xw, lane - 1);
+            wave_sync();
+            continue;
+        }
         if (!done) {
             if (s > 64 * maxnw) { res.status |= 1u; continue; }
+            res.n_wide += 1u;
             const Wide W = wide_carve(smem, maxnw);
             for (int dir = 0; dir < 2; ++dir) {
                 if (!(dir == 0 ? need_bs : need_sb)) continue;

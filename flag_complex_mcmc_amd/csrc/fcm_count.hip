@@ -158,6 +158,7 @@ typedef int (*fcm_step_launcher)(const FcmStepParams *, void *);
 #define FCM_DECL_STEP(tag) int fcm_launch_step_##tag##_0(const FcmStepParams *, void *); int fcm_launch_step_##tag##_1(const FcmStepParams *, void *);
 extern "C" {
 FCM_DECL_STEP(6) FCM_DECL_STEP(14) FCM_DECL_STEP(x2) FCM_DECL_STEP(x3) FCM_DECL_STEP(x4) FCM_DECL_STEP(x5) FCM_DECL_STEP(x6)
+int fcm_launch_step_6_2(const FcmStepParams *, void *); int fcm_launch_step_14_2(const FcmStepParams *, void *);
 int fcm_launch_step_m2_0(const FcmStepParams *, void *); int fcm_launch_step_m3_0(const FcmStepParams *, void *);
 int fcm_launch_step_m4_0(const FcmStepParams *, void *); int fcm_launch_step_m5_0(const FcmStepParams *, void *);
 int fcm_launch_step_m6_0(const FcmStepParams *, void *);
@@ -181,6 +182,7 @@ extern "C" int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, voi
                                                 fcm_launch_step_n5_0, fcm_launch_step_n6_0};   // longer rows
         return (p->stride32 == 32u ? mc : nc)[tmax - 2](p, stream);
     }
+    if (c && p->xw_ws) return tmax <= 6 ? fcm_launch_step_6_2(p, stream) : fcm_launch_step_14_2(p, stream);   // clique moves on a graph with a local set beyond 256 vertices
     if (tmax >= 2 && tmax <= 6) return exact[tmax - 2][c](p, stream);
     if (tmax <= 6) return c ? fcm_launch_step_6_1(p, stream) : fcm_launch_step_6_0(p, stream);
     return c ? fcm_launch_step_14_1(p, stream) : fcm_launch_step_14_0(p, stream);

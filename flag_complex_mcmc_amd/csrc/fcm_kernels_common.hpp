@@ -935,7 +935,7 @@ __device__ __forceinline__ void wide_add(const Wide W, const u32 *rows, u32 stri
 // MINW = minimum waves per SIMD the register allocator must leave room for.
 // CLIQUE = true adds the clique moves (fcm_clique.hpp); the simple-move kernel
 // is compiled without them and keeps its register allocation.
-template <int MAXT, int MINW, bool CLIQUE, bool EXACT>
+template <int MAXT, int MINW, int CLIQUE, bool EXACT>   // CLIQUE: 0 simple moves only, 1 clique moves, 2 clique moves incl. local sets of 257..1024 vertices
 __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];  // fcm_lds_words(p.maxnw) words
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     u64 sampled = st_g[0], accepted = st_g[1], n_empty = st_g[2], n_flip = st_g[3], n_dmove = st_g[4], sum_k = st_g[5];
     u64 n_cperm = st_g[8], n_cswap = st_g[9], n_changes = st_g[10];
     u64 n_wide = st_g[12], n_big = st_g[13];   // diagnostics: wide evaluations, local sets beyond 48 vertices
-    u32 *slot_of = CLIQUE ? p.slot_of + (size_t)chain * p.U : nullptr;
+    u32 *slot_of = CLIQUE != 0 ? p.slot_of + (size_t)chain * p.U : nullptr;
     u32 count_len = (u32)st_g[6];
     u32 status = (u32)st_g[7];
 
@@ -1218,15 +1218,16 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 }
             } else {
                 // ---- clique_permute / clique_swap (src/lib.rs:214-290) -------
-                if constexpr (CLIQUE) {
+                if constexpr (CLIQUE != 0) {
                     const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
 #ifdef FCM_STAMP
                     u64 *clq_sacc = stamp_acc, *clq_stt = &stamp_t;
 #else
                     u64 *clq_sacc = nullptr, *clq_stt = nullptr;
 #endif
-                    const CliqueResult cr = clique_propose<MAXT>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta, es, clq_sacc, clq_stt, &guard);
+                    const CliqueResult cr = clique_propose<MAXT, CLIQUE == 2>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta, es, clq_sacc, clq_stt, &guard);
                     status |= cr.status;
+                    n_wide += cr.n_wide;
                     if (cr.nchg > 0) {
                         nonempty = true;
                         clq_npairs = cr.npairs;
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     in_bounds = true;
                     cnt = ncnt;
                     if (move >= 2) {
-                        if constexpr (CLIQUE) {  // bits are already in place; hand over the reciprocal-pair slots
+                        if constexpr (CLIQUE != 0) {  // bits are already in place; hand over the reciprocal-pair slots
                             const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
                             status |= clique_update_slots(dbl, slot_of, CL, clq_npairs, lane);
                         }
@@ -1303,7 +1304,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                                 *ps |= bs;
                             }
                             if (is_dmove) {
-                                if constexpr (CLIQUE) {
+                                if constexpr (CLIQUE != 0) {
                                     slot_of[dbl[c_slot]] = FCM_NOSLOT;
                                     slot_of[c_newdbl] = c_slot;
                                 }
@@ -1313,7 +1314,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         wave_sync();
                     }
                 } else if (move >= 2) {
-                    if constexpr (CLIQUE) {
+                    if constexpr (CLIQUE != 0) {
                         const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
                         clique_revert(rows, stride32, CL, clq_npairs, lane);
                     }

@@ -1,5 +1,5 @@
 // fcm_step_variant.hip — one instantiation of the step kernel per object file, so the variants
-// compile in parallel.  -DFCM_TAG=<name> -DFCM_MAXT=<t> -DFCM_EXACT=0|1 -DFCM_CLIQUE=0|1:
+// compile in parallel.  -DFCM_TAG=<name> -DFCM_MAXT=<t> -DFCM_EXACT=0|1 -DFCM_CLIQUE=0|1|2 (2: clique moves incl. local sets of 257..1024 vertices):
 //   EXACT=1: the tracked depth tmax (= count entries - 2) IS FCM_MAXT, a compile-time constant: the
 //            clique walk has exactly that many levels and no depth checks (tags x2_0 .. x6_1);
 //   EXACT=0: tmax <= FCM_MAXT at run time (tags 6_0, 14_0, 6_1, 14_1).
@@ -34,7 +34,7 @@ extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *
 {
     size_t words = fcm_lds_words(p->maxnw);
     if (FCM_CLIQUE) words += fcm_clique_lds_words(p->chg_cap);
-    fcm_step_kernel<FCM_MAXT, FCM_MINW, FCM_CLIQUE != 0, FCM_EXACT != 0>
+    fcm_step_kernel<FCM_MAXT, FCM_MINW, FCM_CLIQUE, FCM_EXACT != 0>
         <<<dim3(p->nchains), dim3(WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
     return (int)hipGetLastError();
 }

@@ -212,4 +212,22 @@ __device__ __forceinline__ void xw_add(u64 *ws, const u32 *rows, u32 stride32, c
     xw_set(X, ib, ia, true, lane);
     xw_dfs(X, xw_classify(X, ib, ia, s, lane), tmax, +1, lane);
 }
+// one evaluation of an edge present in the bitmap (a changed pair of a clique move): sign * (#simplices through it) is added
+// to the counts; keep_counts: those of the move's earlier pairs stay.  fwd = 1: big->small.
+__device__ __forceinline__ bool xw_edge(u64 *ws, const u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small, u32 fwd,
+                                        int sign, int lane, int tmax, bool keep_counts)
+{
+    const int s = k + 2;
+    const XWide X = xw_carve(ws, s);
+    long long keep = 0;
+    if (keep_counts && lane < 16) keep = X.cnt[lane];
+    xw_load_list(X, nb, off, k, big, small, lane);
+    if (keep_counts && lane < 16) X.cnt[lane] = keep;
+    xw_sync();
+    xw_build(X, rows, stride32, s, lane);
+    const int iu = fwd ? k : k + 1, iv = fwd ? k + 1 : k;
+    const bool present = xw_has(X, iu, iv);
+    xw_dfs(X, xw_classify(X, iu, iv, s, lane), tmax, sign, lane);
+    return present;
+}
 __device__ __forceinline__ long long xw_count(u64 *ws, int idx) { return xw_carve(ws, 64).cnt[idx]; }

@@ -242,14 +242,12 @@ def test_unsupported_inputs_fail_loudly(fcm):
     with pytest.raises(fcm.FcmError) as ei:
         fcm.MCMCSampler(big, fcm.Bounds([20], [20]))
     assert ei.value.code == 4
-    # a common neighbourhood beyond 1022 vertices (simple moves), beyond 254 with clique moves on
+    # a common neighbourhood beyond 1022 vertices, with either move mix
     t = 1100
     book = [(0, 1)] + [(0, w) for w in range(2, t)] + [(1, w) for w in range(2, t)]
     with pytest.raises(fcm.FcmError) as ei:
         fcm.MCMCSampler(fcm.Graph.from_edges(t, book), fcm.Bounds([t], [t]))
     assert ei.value.code == 4
-    t = 300
-    book = [(0, 1)] + [(0, w) for w in range(2, t)] + [(1, w) for w in range(2, t)]
     with pytest.raises(fcm.FcmError) as ei:
         fcm.MCMCSampler(fcm.Graph.from_edges(t, book), fcm.Bounds([t], [t]), move_weights=fcm.MOVE_DISTRIBUTION)
     assert ei.value.code == 4
@@ -305,6 +303,19 @@ def test_local_sets_beyond_256_vertices(fcm, oracle, monkeypatch, t, p_page, mw)
     assert s.info["k_max"] == t - 2 and s.info["waves_per_chain"] == int(mw)
     st = s.stats()
     assert (st["status"] == 0).all() and st["n_wide"].sum() > 0, "the hub pair was never evaluated"
+
+
+@pytest.mark.parametrize("t,p_page", [(300, 0.008), (700, 0.003)])
+def test_clique_moves_with_local_sets_beyond_256_vertices(fcm, oracle, t, p_page):
+    """The same hub pair under the reference's default move mix: {0, 1, page} are maximal cliques, so clique moves change
+    the pair {0, 1} itself, whose local set of t vertices takes the HBM-workspace evaluator inside a clique move
+    (fcm_xwide.hpp: xw_edge).  Oracle twins, tolerance 0."""
+    e = _book_graph(t, p_page, seed=t)
+    s, tw = _run_parity(fcm, oracle, t, e, n_chains=3, steps=[64, 1500], seed=t + 2, weights=(0.0, 0.0, 0.75, 0.25), relaxation=0.3)   # clique moves only: every wide evaluation is a clique move's
+    assert s.info["k_max"] == t - 2 and s.info["waves_per_chain"] == 1
+    st = s.stats()
+    assert (st["status"] == 0).all() and st["n_cperm"].sum() + st["n_cswap"].sum() > 0
+    assert st["n_wide"].sum() > 0, "no clique move changed the hub pair"
 
 
 @pytest.mark.parametrize("t", [202, 258, 602, 1026])
