@@ -491,6 +491,9 @@ struct EvScal { int d1, d2; };
 // lane, so that the first loop level disappears and only the short deeper loops remain per lane.
 // The list sits behind Hp (FCM_PAIR_CAP 16-bit entries).
 #define FCM_PAIR_CAP 256
+#ifndef FCM_SEAT_BRANCHY
+#define FCM_SEAT_BRANCHY 0
+#endif
 template <int MAXT>
 __device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1], EvScal &es,
                                            u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
@@ -536,15 +539,22 @@ __device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int 
     }
 }
 
-// row bit `pos` := mask bit `orig` (both wave-uniform: the half words involved are picked by scalar branches; the empty
-// asm statements keep hipcc from turning them into selects over both halves)
+// row bit `pos` := mask bit `orig` (both wave-uniform).  On the 64-bit values, five VALU and nothing else: picking the
+// half words by scalar branches takes two VALU but a dozen SALU and four branches, and a scalar instruction costs this
+// kernel twice what a vector one does (tools: MW_PROBE 7/8).
 __device__ __forceinline__ void seat_bit(u32 blo, u32 bhi, u32 &rlo, u32 &rhi, int orig, int pos)
 {
+#if FCM_SEAT_BRANCHY
     u32 t;
     if (orig < 32) { t = __builtin_amdgcn_ubfe(blo, (u32)orig, 1u); asm volatile("" : "+v"(t)); }
     else { t = __builtin_amdgcn_ubfe(bhi, (u32)(orig - 32), 1u); asm volatile("" : "+v"(t)); }
     if (pos < 32) { rlo |= t << pos; asm volatile("" : "+v"(rlo)); }
     else { rhi |= t << (pos - 32); asm volatile("" : "+v"(rhi)); }
+#else
+    const u64 b = (u64)blo | ((u64)bhi << 32);
+    const u64 t = ((b >> orig) & 1ull) << pos;
+    rlo |= (u32)t; rhi |= (u32)(t >> 32);
+#endif
 }
 
 // E(G, u->v): builds the split graph for classes `c` into Hp and counts.
