@@ -385,6 +385,9 @@ __device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, in
 // s upwards.  If they do not fit in 64 the caller falls back to the wide path.
 // ---------------------------------------------------------------------------
 #define FCM_NEEDS_WIDE (-2)
+#ifndef FCM_SEAT_BRANCHY
+#define FCM_SEAT_BRANCHY 0   // 1: pick 32-bit halves by scalar branches (fewer VALU, more SALU and branches)
+#endif
 
 struct Cls { u64 P, M, S; };
 
@@ -393,8 +396,12 @@ struct Cls { u64 P, M, S; };
 // ballot of bit i (wave-uniform) of a 64-bit per-lane mask: one v_and on the half that holds it and one v_cmp
 __device__ __forceinline__ u64 ballot_bit(u64 h, int i)
 {
+#if FCM_SEAT_BRANCHY
     const u32 m = 1u << (i & 31);
     return i < 32 ? ballot(((u32)h & m) != 0u) : ballot(((u32)(h >> 32) & m) != 0u);
+#else
+    return ballot(((h >> i) & 1ull) != 0ull);   // (a 64-bit shift rather than a scalar branch on the half: see seat_bit)
+#endif
 }
 // per-lane bool from a wave-uniform mask: the SGPR pair is used as the select mask directly, no VALU
 __device__ __forceinline__ bool lane_in(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
@@ -491,9 +498,6 @@ struct EvScal { int d1, d2; };
 // lane, so that the first loop level disappears and only the short deeper loops remain per lane.
 // The list sits behind Hp (FCM_PAIR_CAP 16-bit entries).
 #define FCM_PAIR_CAP 256
-#ifndef FCM_SEAT_BRANCHY
-#define FCM_SEAT_BRANCHY 0
-#endif
 template <int MAXT>
 __device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1], EvScal &es,
                                            u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
