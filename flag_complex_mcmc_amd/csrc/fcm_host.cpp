@@ -822,7 +822,6 @@ try {
     }
     if (kmax + 2 > FCM_MAX_LOCAL)
         return fail(FCM_ERR_UNSUPPORTED, "an edge has %u common neighbours; this build supports at most %d", kmax, FCM_MAX_LOCAL - 2);
-    const bool clique_wanted = cfg->move_weights[2] > 0.0 || cfg->move_weights[3] > 0.0;
     // at least two mask words of LDS: the one-word path falls back to the wide one when the
     // per-class copies of multi-class vertices do not fit in 64 nodes.  Local sets beyond 256 vertices take the
     // evaluator with its masks in a per-chain workspace (fcm_xwide.hpp), allocated only then.
