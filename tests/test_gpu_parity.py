@@ -702,6 +702,18 @@ def test_multi_wave_conflict_paths_trajectory_parity(fcm, oracle, monkeypatch, W
         assert recheck > 0 and held > 0, (recheck, held)
 
 
+@pytest.mark.parametrize("cfg,chains,props", [(2, 96, 1 << 15), (3, 48, 1 << 14)])
+def test_multi_wave_soak_every_W_ends_where_one_wave_ends(fcm, cfg, chains, props):
+    """tools/mw_soak.py: BASELINE graphs (n = 1000: exact lookup maps; n = 4000: supersets), W = 2, 4, 8, 16 against the
+    one-wave kernel -- counts, counters, slot lists and whole bitmaps of three chains after tens of thousands of proposals
+    per chain, with thousands of records re-checked and staged conflicts waited for on the way."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("mw_soak", os.path.join(os.path.dirname(__file__), "..", "tools", "mw_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.soak(cfg, chains, props, say=lambda m: None)
+
+
 @pytest.mark.parametrize("W", [2, 16])
 def test_multi_wave_equals_one_wave_at_scale(fcm, monkeypatch, W):
     """Config-3 graph (local sets of 65 vertices included: the wide path under the token): the multi-wave kernel must
