@@ -1006,12 +1006,18 @@ try {
     I.lossless = lossless ? 1 : 0;
     I.n_chains = C;
     // Simple moves run with several waves per chain (fcm_step_mw.hpp): W consecutive proposals in flight, decided in order.
-    // W is chosen so that chains x W fills the chip's 8192 wave slots without passing them: 8 up to 1024 chains, 4 up to 2048, 2 above; 16 up to
-    // 512 chains on graphs of more than 1024 vertices (on smaller ones more than 8 proposals in flight buy nothing: the in-order decisions are the limit by then).
+    // W is chosen so that chains x W fills the chip's 8192 wave slots without passing them: 8 up to 1024 chains, 4 up to 2048, 2 above; 16 on
+    // graphs of more than 1024 vertices whose proposals are memory-heavy, or up to 256 chains (on smaller graphs more than 8 proposals in flight buy nothing: the in-order decisions are the limit by then).
     // FCM_MW=<1|2|4|8|16> overrides (1 = the one-wave kernel).
     {
         uint32_t W = C > 2048 ? 2u : (C > 1024 ? 4u : 8u);   // the largest of 8, 4, 2 with chains x W <= 8192 (all resident)
-        if (C <= 512 && p.stride32 > 32) W = 16u;              // rows longer than a cache line (n > 1024): a proposal is mostly memory round trips, twice the waves still pay
+        if (p.stride32 > 32) {
+            // rows longer than a cache line (n > 1024).  If a build touches many lines (config 3: 42 rows x 4 lines) a proposal is
+            // mostly memory round trips and 16 of them in flight per chain pay at any chain count, even when the chains then
+            // run in several rounds (4096 chains of config 3: +21 % over W = 2); otherwise only while the chip is not full.
+            const double rows_touched = I.k_mean + 2.0, lines = rows_touched * std::min(rows_touched, (double)p.stride32 / 32.0);
+            if (lines >= 64.0 || C <= 256) W = 16u;
+        }
         if (const char *e = getenv("FCM_MW")) {
             const int v = atoi(e);
             W = (v == 2 || v == 4 || v == 8 || v == 16) ? (uint32_t)v : 1u;

@@ -247,7 +247,7 @@ typedef struct {
     uint32_t n_chains;
     uint32_t waves_per_chain;  /* 1: one wave per chain (fcm_step_kernel); W = 2, 4, 8, 16: the multi-wave kernel (fcm_step_mw_kernel),
                                   W consecutive proposals of a chain in flight, decided in order.  The library chooses (simple
-                                  moves, <= 8 count entries; the largest W of 8, 4, 2 with chains x W <= 8192 wave slots, 16 up to 512 chains on graphs of more than 1024 vertices); environment FCM_MW=<W> overrides
+                                  moves, <= 8 count entries; the largest W of 8, 4, 2 with chains x W <= 8192 wave slots; 16 on graphs of more than 1024 vertices whose builds touch many cache lines, or with up to 256 chains); environment FCM_MW=<W> overrides
                                   (1 = one-wave kernel).  Trajectories are identical whatever W is. */
 } fcm_sampler_info;
 int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out);

@@ -668,7 +668,7 @@ def test_multi_wave_kernel_is_selected_and_switchable(fcm, monkeypatch):
     fcb = gb.flagser_count()
     bb = fcm.Bounds.calculate(gb, fcb, fcm.Bounds.target(fcb, 0.05))
     assert fcm.MCMCSampler(gb, bb, n_chains=2, seed=1).info["waves_per_chain"] == (16 if len(fcb) - 2 >= 2 else 1)
-    assert fcm.MCMCSampler(gb, bb, n_chains=513, seed=1).info["waves_per_chain"] == (8 if len(fcb) - 2 >= 2 else 1)
+    assert fcm.MCMCSampler(gb, bb, n_chains=257, seed=1).info["waves_per_chain"] == (8 if len(fcb) - 2 >= 2 else 1)   # (a sparse graph: few lines per build)
     assert fcm.MCMCSampler(g, b, n_chains=2048, seed=1).info["waves_per_chain"] == 4
     assert fcm.MCMCSampler(g, b, n_chains=1024, seed=1).info["waves_per_chain"] == 8
     assert fcm.MCMCSampler(g, b, n_chains=3000, seed=1).info["waves_per_chain"] == 2      # 3000 x 4 would not all be resident
