@@ -94,6 +94,27 @@ struct CliqueResult {
     u32 n_wide;       // pairs of this move that took a multi-word evaluator
 };
 
+// One direction of a changed pair on the wide evaluator (its counts are 64-bit): the edge is in the bitmap while it is
+// counted -- set before an addition, cleared after a removal.  The count changes go to res.wide_d.
+__device__ __forceinline__ void clique_dir_wide(u64 *smem, int maxnw, u32 *rows, u32 stride32, const u32 *nb, u32 off, int k, u32 big, u32 small,
+                                                u32 fwd, bool add, u32 *word, u32 bit, int lane, int tmax, CliqueResult &res)
+{
+    const Wide W = wide_carve(smem, maxnw);
+    if (add) {
+        if (lane == 0) *word |= bit;
+        wave_sync();
+    }
+    wide_zero_counts(W, lane);
+    if (!wide_edge(W, rows, stride32, nb, off, k, big, small, fwd, add ? +1 : -1, lane, tmax)) res.status |= 1u;
+    if (lane >= 2 && lane < 16 && lane - 1 <= tmax) res.wide_d += W.cnt[lane - 1];
+    wave_sync();
+    if (!add) {
+        if (lane == 0) *word &= ~bit;
+        wave_sync();
+    }
+    res.n_wide += 1u;
+}
+
 // Builds the changed-pair list of a clique move and applies it to the bitmap,
 // adding the simplex-count change to `delta` (fast evaluations) and res.wide_d
 // (wide).  move == 2: clique_permute, 3: clique_swap.
@@ -293,7 +314,19 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
             csb.M = inB & outS & nbm;
             if ((!need_bs || extras_fit(cbs, s)) && (!need_sb || extras_fit(csb, s))) {
                 if (need_bs) eval_nodes<MAXT>(myH, Hp, cbs, k, tmax, n_bs ? +1 : -1, lane, delta, es, nullptr, nullptr, guard);
+                if constexpr (MAXT >= 7) {   // the bound on the 32-bit counts was passed: this direction on the wide path (64-bit counts)
+                    if (need_bs && guard && guard->tripped) {
+                        guard->tripped = 0u;
+                        clique_dir_wide(smem, maxnw, rows, stride32, p.nb, off, k, big, small, 1u, n_bs != 0u, wbs, bit_s, lane, tmax, res);
+                    }
+                }
                 if (need_sb) eval_nodes<MAXT>(myH, Hp, csb, k, tmax, n_sb ? +1 : -1, lane, delta, es, nullptr, nullptr, guard);
+                if constexpr (MAXT >= 7) {
+                    if (need_sb && guard && guard->tripped) {
+                        guard->tripped = 0u;
+                        clique_dir_wide(smem, maxnw, rows, stride32, p.nb, off, k, big, small, 0u, n_sb != 0u, wsb, bit_b, lane, tmax, res);
+                    }
+                }
                 if (lane == 0) {
                     if (need_bs) *wbs = n_bs ? (vbs | bit_s) : (vbs & ~bit_s);
                     if (need_sb) *wsb = n_sb ? (vsb | bit_b) : (vsb & ~bit_b);

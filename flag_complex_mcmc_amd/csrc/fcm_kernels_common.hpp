@@ -511,9 +511,12 @@ __device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int 
     } else {
         const int incl = wave_scan_i32(nch);
         const int tp = __builtin_amdgcn_readlane(incl, 63);
+        if constexpr (MAXT >= 7) {   // bound first: an evaluation that passes it changes nothing (the caller counts it on the wide path)
+            if (tmax >= 3 && tp != 0) fcm_count_guard(nch, tp, tmax, guard);
+            if (guard && guard->tripped) return;
+        }
         es.d2 += sign * tp;
         if (tmax < 3 || tp == 0) return;
-        if constexpr (MAXT >= 7) fcm_count_guard(nch, tp, tmax, guard);
         if (tp <= FCM_PAIR_CAP) {
             // scatter the arcs: 32-bit halves (one v_ffbl per arc instead of a 64-bit find-first-set)
             unsigned short *list = (unsigned short *)(Hp + WAVE) + (incl - nch);
@@ -606,8 +609,13 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
     Hp[lane] = (u64)rlo | ((u64)rhi << 32);
     wave_sync();
     FCM_STAMP_PTR(3);                                                  // (flips-only diagnostic) classes, seating, split rows
-    if (tmax >= 1) es.d1 += sign * __popcll(G0);
-    walk_nodes<MAXT>(rlo, rhi, Hp, tmax, sign, lane, delta, es, sacc, stt, guard);
+    if constexpr (MAXT >= 7) {
+        walk_nodes<MAXT>(rlo, rhi, Hp, tmax, sign, lane, delta, es, sacc, stt, guard);
+        if (tmax >= 1 && !(guard && guard->tripped)) es.d1 += sign * __popcll(G0);
+    } else {
+        if (tmax >= 1) es.d1 += sign * __popcll(G0);
+        walk_nodes<MAXT>(rlo, rhi, Hp, tmax, sign, lane, delta, es, sacc, stt, guard);
+    }
     wave_sync();
 }
 
@@ -1088,6 +1096,13 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 #else
                         res = flip_eval<MAXT>(rrows, stride32, Lv, k, Hp, lane, tmax, delta, es, &guard);
 #endif
+                        if (MAXT >= 7 && guard.tripped) {   // the bound on the 32-bit local counts was passed (it is generous): count this
+                            guard.tripped = 0u;             // proposal with the wide evaluator, whose counts are 64-bit
+#pragma unroll
+                            for (int q = 0; q <= MAXT; ++q) delta[q] = 0;
+                            es.d1 = es.d2 = 0;
+                            res = FCM_NEEDS_WIDE;
+                        }
                     }
                     if (res == FCM_NEEDS_WIDE) {
                         if (k + 2 <= 64 * maxnw) {
@@ -1200,6 +1215,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                                 const int r2 = add_eval_built<MAXT>(myH2, Lv2, rk, rfwd, dfrom, dto, Hp, lane, tmax, delta, es, &guard);
                                 go_wide = r2 == FCM_NEEDS_WIDE;
                             }
+                            if (MAXT >= 7 && guard.tripped) { guard.tripped = 0u; go_wide = true; }   // (as for flips: 64-bit counts on the wide path)
                         }
                         if (go_wide) {
 #pragma unroll

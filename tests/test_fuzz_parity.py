@@ -1,0 +1,48 @@
+"""Randomized differential test: random small graphs, move mixes, bounds relaxations, chain counts, launch sizes and
+waves per chain against oracle twins (tolerance 0: counts, counters, edges, slot lists after every launch).  A dozen
+cases by default; FCM_FUZZ_CASES=<n> and FCM_FUZZ_SEED=<s> run a campaign (the round-2 campaign: 400 cases, seed 2)."""
+import os
+import numpy as np
+import pytest
+
+from test_gpu_parity import _run_parity
+
+pytestmark = pytest.mark.gpu
+
+NCASES = int(os.environ.get("FCM_FUZZ_CASES", "12"))
+SEED0 = int(os.environ.get("FCM_FUZZ_SEED", "1"))
+
+
+def _case(i):
+    rng = np.random.default_rng([SEED0, i])
+    n = int(rng.integers(6, 70))
+    p = float(rng.uniform(0.08, 0.5)) if n < 30 else float(rng.uniform(0.05, 0.25))
+    mix = int(rng.integers(0, 5))
+    weights = [(0.5, 0.5, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (0.0, 1.0, 0.0, 0.0), (0.1, 0.1, 0.6, 0.2), (0.25, 0.25, 0.25, 0.25)][mix]
+    W = [1, 2, 4, 8, 16][int(rng.integers(0, 5))]
+    steps = [int(x) for x in rng.integers(1, 400, size=int(rng.integers(2, 5)))] + [int(rng.integers(400, 1500))]
+    return dict(n=n, p=p, gseed=int(rng.integers(0, 1 << 30)), weights=weights, W=W, steps=steps, chains=int(rng.integers(1, 5)),
+                seed=int(rng.integers(0, 1 << 30)), relaxation=float(rng.choice([0.01, 0.05, 0.3])), first=int(rng.integers(0, 1000)))
+
+
+@pytest.mark.parametrize("i", range(NCASES))
+def test_random_case_against_oracle_twins(fcm, oracle, monkeypatch, i):
+    from flag_complex_mcmc_amd import graphs
+    c = _case(i)
+    e = graphs.random_with_p(c["n"], c["p"], seed=c["gseed"])
+    if len(e) < 2:
+        pytest.skip("empty graph")
+    monkeypatch.setenv("FCM_MW", str(c["W"]))
+    try:
+        s, tw = _run_parity(fcm, oracle, c["n"], e, n_chains=c["chains"], steps=c["steps"], seed=c["seed"], weights=c["weights"],
+                            relaxation=c["relaxation"], first_chain_id=c["first"])
+    except ValueError as ex:
+        if "would panic in the reference" in str(ex):   # (the oracle's Bounds::calculate: the reference panics on this input)
+            pytest.skip(str(ex))
+        raise
+    except fcm.FcmError as ex:
+        # inputs on which the reference itself panics (Bounds::calculate on some tiny graphs) or that this build refuses loudly
+        if ex.code in (4, 6):
+            pytest.skip("refused: %s" % ex)
+        raise
+    assert (s.stats()["status"] == 0).all(), c

@@ -825,6 +825,26 @@ def test_local_count_guard_refuses_instead_of_wrapping(fcm, monkeypatch, mw):
     assert ei.value.code == 8 and "0x100" in str(ei.value)
 
 
+def test_deep_kernels_count_on_the_wide_path_when_the_bound_is_passed(fcm, oracle, monkeypatch):
+    """Kernels that track more than 6 levels bound every walk's counts by arcs x (max children)^(t-2) -- generous: dense
+    little graphs pass 2^31 by the bound long before their counts do (found by the randomized campaign,
+    tests/test_fuzz_parity.py).  Such a proposal is then counted by the wide evaluator, whose counts are 64-bit, instead of
+    being refused.  Here the limit is lowered through the test hook so that every proposal takes that way: oracle twins."""
+    from flag_complex_mcmc_amd import graphs
+    n = 22
+    e = graphs.random_with_p(n, 0.6, seed=2)
+    assert len(fcm.Graph.from_edges(n, e).flagser_count()) >= 9          # more than 6 tracked levels: the generic kernels
+    monkeypatch.setenv("FCM_MW", "1")
+    monkeypatch.setenv("FCM_TEST_GUARD_LIMIT", "40")
+    s, tw = _run_parity(fcm, oracle, n, e, n_chains=2, steps=[1, 64, 800], seed=9, relaxation=0.3)
+    st = s.stats()
+    assert (st["status"] == 0).all() and st["n_wide"].sum() > 100
+    # the same inside clique moves: a changed pair's direction that passes the bound is counted on the wide path
+    s, tw = _run_parity(fcm, oracle, n, e, n_chains=2, steps=[1, 64, 400], seed=10, weights=(0.0, 0.0, 0.75, 0.25), relaxation=0.3)
+    st = s.stats()
+    assert (st["status"] == 0).all() and st["n_wide"].sum() > 100
+
+
 def test_count_kernel_counts_past_2_to_31_per_edge(fcm):
     """Complete 7-partite graph, parts of 7, every pair reciprocal, on 49 vertices: count[d] = C(7,d+1) 7^(d+1) (d+1)!
     -- 4.2e9 6-simplices in all and far more than 2^31 / 64 per lane of the counting wave: the per-lane accumulators
