@@ -13,14 +13,21 @@ NCASES = int(os.environ.get("FCM_FUZZ_CASES", "12"))
 SEED0 = int(os.environ.get("FCM_FUZZ_SEED", "1"))
 
 
+MEDIUM = os.environ.get("FCM_FUZZ_MEDIUM", "0") == "1"   # campaign option: graphs of 100..700 vertices, local sets of 10..60 vertices
+
+
 def _case(i):
     rng = np.random.default_rng([SEED0, i])
-    n = int(rng.integers(6, 70))
-    p = float(rng.uniform(0.08, 0.5)) if n < 30 else float(rng.uniform(0.05, 0.25))
+    if MEDIUM:
+        n = int(rng.integers(100, 700))
+        p = float(np.sqrt(rng.uniform(10.0, 60.0) / n) / 2.0)     # |N(a) cap N(b)| about n (2p)^2
+    else:
+        n = int(rng.integers(6, 70))
+        p = float(rng.uniform(0.08, 0.5)) if n < 30 else float(rng.uniform(0.05, 0.25))
     mix = int(rng.integers(0, 5))
     weights = [(0.5, 0.5, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (0.0, 1.0, 0.0, 0.0), (0.1, 0.1, 0.6, 0.2), (0.25, 0.25, 0.25, 0.25)][mix]
     W = [1, 2, 4, 8, 16][int(rng.integers(0, 5))]
-    steps = [int(x) for x in rng.integers(1, 400, size=int(rng.integers(2, 5)))] + [int(rng.integers(400, 1500))]
+    steps = [int(x) for x in rng.integers(1, 400, size=int(rng.integers(2, 5)))] + [int(rng.integers(400, 4000 if MEDIUM else 1500))]
     return dict(n=n, p=p, gseed=int(rng.integers(0, 1 << 30)), weights=weights, W=W, steps=steps, chains=int(rng.integers(1, 5)),
                 seed=int(rng.integers(0, 1 << 30)), relaxation=float(rng.choice([0.01, 0.05, 0.3])), first=int(rng.integers(0, 1000)))
 
