@@ -40,9 +40,23 @@ def test_random_case_against_oracle_twins(fcm, oracle, monkeypatch, i):
     if len(e) < 2:
         pytest.skip("empty graph")
     monkeypatch.setenv("FCM_MW", str(c["W"]))
+    bounds = None
+    rng = np.random.default_rng([SEED0, i, 7])
+    if rng.random() < 0.35:
+        # hand-made bounds around the initial counts: tight (most proposals rejected), and now and then not even containing
+        # the initial state (the chain then accepts nothing but empty transitions until a move brings it inside -- it cannot:
+        # every non-empty proposal is checked against the bounds -- src/lib.rs:185-191)
+        fc = oracle.Graph.from_edges(c["n"], e).flagser_count()
+        width = [int(rng.integers(0, 1 + max(1, v // int(rng.choice([4, 20, 200]))))) for v in fc]
+        lo = [max(0, v - w) for v, w in zip(fc, width)]
+        hi = [v + w for v, w in zip(fc, width)]
+        lo[0], hi[0], lo[1], hi[1] = fc[0], fc[0], fc[1], fc[1]
+        if rng.random() < 0.2 and len(fc) > 2:
+            lo[2] = fc[2] + 1; hi[2] = fc[2] + 1 + width[2]
+        bounds = (lo, hi)
     try:
         s, tw = _run_parity(fcm, oracle, c["n"], e, n_chains=c["chains"], steps=c["steps"], seed=c["seed"], weights=c["weights"],
-                            relaxation=c["relaxation"], first_chain_id=c["first"])
+                            relaxation=c["relaxation"], first_chain_id=c["first"], bounds=bounds)
     except ValueError as ex:
         if "would panic in the reference" in str(ex):   # (the oracle's Bounds::calculate: the reference panics on this input)
             pytest.skip(str(ex))
