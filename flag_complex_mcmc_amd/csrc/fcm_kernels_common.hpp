@@ -952,6 +952,12 @@ __device__ __forceinline__ void wide_add(const Wide W, const u32 *rows, u32 stri
 #include "fcm_clique.hpp"
 
 // ===========================================================================
+__device__ __forceinline__ u32 mw_lds_addr_of(const void *p) { return (u32)(size_t)(__attribute__((address_space(3))) const char *)p; }
+// tallies of the one-wave kernel, u32 words in LDS: counters in words 0..9 (the first eight count events), then the OR
+// of "count entry d was non-zero after a transition" masks and of the proposals' status words
+enum { OT_ACCEPTED = 0, OT_EMPTY, OT_FLIP, OT_DMOVE, OT_CPERM, OT_CSWAP, OT_WIDE, OT_BIG, OT_SUMK, OT_CHANGES, OT_NZ, OT_STATUS };
+#define FCM_TALLY_LDS_WORDS 8u   // u64 words
+
 // Step kernel
 // ===========================================================================
 // MINW = minimum waves per SIMD the register allocator must leave room for.
@@ -981,12 +987,13 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     const u64 bmin = cl ? p.bmin[lane] : 0ull;
     const u64 bmax = cl ? p.bmax[lane] : ~0ull;
 
-    u64 sampled = st_g[0], accepted = st_g[1], n_empty = st_g[2], n_flip = st_g[3], n_dmove = st_g[4], sum_k = st_g[5];
-    u64 n_cperm = st_g[8], n_cswap = st_g[9], n_changes = st_g[10];
-    u64 n_wide = st_g[12], n_big = st_g[13];   // diagnostics: wide evaluations, local sets beyond 48 vertices
+    u64 sampled = st_g[0];
+    // The launch's tallies live in 16 words of LDS (OT_*: one masked ds_add and one ds_or per proposal), not in a dozen
+    // 64-bit scalars carried -- spilled -- around the whole loop; they are added to the chain's stats row at the end.
+    u32 *tly = (u32 *)(smem + fcm_lds_words(p.maxnw) + (CLIQUE != 0 ? fcm_clique_lds_words(p.chg_cap) : 0u));
+    if (lane < 16) tly[lane] = 0u;
+    wave_sync();
     u32 *slot_of = CLIQUE != 0 ? p.slot_of + (size_t)chain * p.U : nullptr;
-    u32 count_len = (u32)st_g[6];
-    u32 status = (u32)st_g[7];
 
     const u32 U = p.U, D = p.D;
     const u64 Mtot = (u64)U + D;
@@ -1046,6 +1053,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             EvScal es = {0, 0};
 
             bool nonempty = false, used_wide = false, used_xw = false;
+            u32 t_sumk = 0u, t_changes = 0u, t_big = 0u, t_wide = 0u, pst = 0u, acc_inc = 0u;   // this proposal's share of the tallies
             // pending commit (uniform)
             u32 c_clr_from = 0, c_clr_to = 0, c_set_from = 0, c_set_to = 0;
             // the two bitmap words a commit rewrites, read while the build is in flight so that the
@@ -1117,15 +1125,15 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             res = -1;
                         }
                     }
-                    if (res < 0) status |= 1u;  // table says adjacent, bitmap says not
+                    if (res < 0) pst |= 1u;  // table says adjacent, bitmap says not
                     if (res > 0) {
                         nonempty = true;
                         c_clr_from = res == 1 ? a : b; c_clr_to = res == 1 ? b : a;
                         c_set_from = c_clr_to; c_set_to = c_clr_from;
                         c_clr_old = res == 1 ? w_ab : w_ba; c_set_old = res == 1 ? w_ba : w_ab;
                         c_have_old = pre;
-                        sum_k += (u64)k;
-                        if (k + 2 > 48) n_big += 1;
+                        t_sumk += (u32)k;
+                        if (k + 2 > 48) t_big = 1u;
                     }
                 }
             } else if (move == 1) {
@@ -1171,7 +1179,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                                 Lv2 = load_list(nb, ce.nb_off, ck, ce.big, ce.small, lane);
                                 myH2 = build_local(rrows, stride32, Lv2, ck + 2, lane);
                                 const u32 f = (u32)(rdlane64(myH2, ck + 1) >> ck) & 1u, bwd = (u32)(rdlane64(myH2, ck) >> (ck + 1)) & 1u;
-                                if (!(f | bwd)) status |= 1u;
+                                if (!(f | bwd)) pst |= 1u;
                                 found = (f ^ bwd) != 0u;
                                 rfwd = f;
                             } else {  // wide candidate: look at its two words directly
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                                     xw_add(xw_ws, rows, stride32, nb, roff, rk, rbig, rsmall, rfwd, dfrom, dto, lane, tmax, true);
                                     used_wide = true; used_xw = true;
                                 } else {
-                                    status |= 1u;
+                                    pst |= 1u;
                                 }
                             } else {
                                 const Wide W = wide_carve(smem, maxnw);
@@ -1238,12 +1246,12 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                             }
                         }
                         FCM_STAMP_AT(5);                               // double move: second build + two evaluations
-                        if (!okd) status |= 2u;  // slot list says reciprocal, bitmap says not
+                        if (!okd) pst |= 2u;  // slot list says reciprocal, bitmap says not
                         c_clr_from = dfrom; c_clr_to = dto;
                         c_set_from = eb; c_set_to = ea;
                         c_slot = slot; c_newdbl = r;
-                        sum_k += (u64)de.k + (u64)rk;
-                        if (dk + 2 > 48 || rk + 2 > 48) n_big += 1;
+                        t_sumk += de.k + (u32)rk;
+                        if (dk + 2 > 48 || rk + 2 > 48) t_big = 1u;
                     }
                 }
             } else {
@@ -1256,35 +1264,34 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     u64 *clq_sacc = nullptr, *clq_stt = nullptr;
 #endif
                     const CliqueResult cr = clique_propose<MAXT, CLIQUE == 2>(p, rows, rrows, smem, CL, move, w1, idx, sampled, gchain, k0, k1, lane, tmax, maxnw, delta, es, clq_sacc, clq_stt, &guard);
-                    status |= cr.status;
-                    n_wide += cr.n_wide;
+                    pst |= cr.status;
+                    t_wide += cr.n_wide;
                     if (cr.nchg > 0) {
                         nonempty = true;
                         clq_npairs = cr.npairs;
                         wide_d = cr.wide_d;
-                        sum_k += cr.sum_k;
-                        n_changes += (u64)cr.nchg;
+                        t_sumk += (u32)cr.sum_k;
+                        t_changes += (u32)cr.nchg;
                     }
                 } else {
-                    status |= 4u;  // this kernel variant was built without the clique moves
+                    pst |= 4u;  // this kernel variant was built without the clique moves
                 }
             }
 
             FCM_STAMP_AT(0);
             // ---- sampled += 1; Bounds::check; accept or drop ---------------
             sampled += 1;
+            u64 nzm = 0ull;
             if (!nonempty) {
-                n_empty += 1;
-                if (in_bounds) accepted += 1;
+                if (in_bounds) acc_inc = 1u;
             } else {
-                if (move == 2) n_cperm += 1; else if (move == 3) n_cswap += 1; else if (is_dmove) n_dmove += 1; else n_flip += 1;
                 long long myd = 0;
                 if (used_xw) {
-                    n_wide += 1;
+                    t_wide += 1u;
                     if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = xw_count(xw_ws, lane - 1);
                     wave_sync();
                 } else if (used_wide) {
-                    n_wide += 1;
+                    t_wide += 1u;
                     const Wide W = wide_carve(smem, maxnw);
                     if (lane >= 2 && lane < 16 && lane - 1 <= tmax) myd = W.cnt[lane - 1];
                     wave_sync();
@@ -1302,20 +1309,18 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 }
                 myd += wide_d;  // clique moves: evaluations that went through the wide path
                 const u64 ncnt = cnt + (u64)myd;
-                if (ballot(cl && myd < 0 && cnt < (u64)(-myd))) status |= 8u;  // reference assert, src/lib.rs:65
+                if (ballot(cl && myd < 0 && cnt < (u64)(-myd))) pst |= 8u;  // reference assert, src/lib.rs:65
                 // flag_count never shrinks in length (src/lib.rs:72-74)
-                const u64 nz = ballot(cl && ncnt != 0ull);
-                const u32 nlen = nz ? (u32)(64 - __clzll((long long)nz)) : 0u;
-                if (nlen > count_len) count_len = nlen;
+                nzm = ballot(cl && ncnt != 0ull);
                 const bool ok = ballot(cl && (ncnt < bmin || ncnt > bmax)) == 0ull;
                 if (ok) {
-                    accepted += 1;
+                    acc_inc = 1u;
                     in_bounds = true;
                     cnt = ncnt;
                     if (move >= 2) {
                         if constexpr (CLIQUE != 0) {  // bits are already in place; hand over the reciprocal-pair slots
                             const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
-                            status |= clique_update_slots(dbl, slot_of, CL, clq_npairs, lane);
+                            pst |= clique_update_slots(dbl, slot_of, CL, clq_npairs, lane);
                         }
                     } else {
                         if (lane == 0) {
@@ -1350,18 +1355,34 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     }
                 }
             }
+            {   // this proposal's tallies: lanes 0..9 add, lanes 10..11 OR (all 64 lanes are active here: uniform branches only)
+                const u32 kind = !nonempty ? (1u << OT_EMPTY) : (move == 2 ? (1u << OT_CPERM) : (move == 3 ? (1u << OT_CSWAP) : (is_dmove ? (1u << OT_DMOVE) : (1u << OT_FLIP))));
+                const u64 im = (u64)(kind | (acc_inc << OT_ACCEPTED) | (t_big << OT_BIG));
+                u32 inc = lane_in(im) ? 1u : 0u;
+                inc = lane_in(1ull << OT_WIDE) ? t_wide : inc;
+                inc = lane_in(1ull << OT_SUMK) ? t_sumk : inc;
+                inc = lane_in(1ull << OT_CHANGES) ? t_changes : inc;
+                const u32 orv = lane_in(1ull << OT_NZ) ? (u32)nzm : pst;
+                const u32 taddr = mw_lds_addr_of(tly) + (u32)lane * 4u;
+                asm volatile("s_mov_b64 exec, 0x3ff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0xc00\n\tds_or_b32 %0, %2\n\ts_mov_b64 exec, -1"
+                             :: "v"(taddr), "v"(inc), "v"(orv) : "memory");
+            }
             FCM_STAMP_AT(6);                                           // reductions, bounds, commit
         }
         FCM_STAMP_AT(7);                                               // (batch boundary)
     }
 
-    if (guard.tripped) status |= 256u;   // a local count may have passed 2^31: refuse rather than wrap
     if (cl) cnt_g[lane] = cnt;
+    wave_sync();
+    const u32 tl = lane < 16 ? tly[lane] : 0u;
+    const u32 nzall = rdlane(tl, OT_NZ);
+    const u32 nlen = nzall ? (u32)(32 - __clz((int)nzall)) : 0u;
+    const u32 stw = rdlane(tl, OT_STATUS) | (guard.tripped ? 256u : 0u);   // (guard: a local count may have passed 2^31: refuse rather than wrap)
     if (lane == 0) {
-        st_g[0] = sampled; st_g[1] = accepted; st_g[2] = n_empty; st_g[3] = n_flip;
-        st_g[4] = n_dmove; st_g[5] = sum_k; st_g[6] = count_len; st_g[7] = status;
-        st_g[8] = n_cperm; st_g[9] = n_cswap; st_g[10] = n_changes;
-        st_g[12] = n_wide; st_g[13] = n_big;
+        st_g[0] = sampled; st_g[1] += rdlane(tl, OT_ACCEPTED); st_g[2] += rdlane(tl, OT_EMPTY); st_g[3] += rdlane(tl, OT_FLIP);
+        st_g[4] += rdlane(tl, OT_DMOVE); st_g[5] += rdlane(tl, OT_SUMK); if (nlen > st_g[6]) st_g[6] = nlen; st_g[7] |= stw;
+        st_g[8] += rdlane(tl, OT_CPERM); st_g[9] += rdlane(tl, OT_CSWAP); st_g[10] += rdlane(tl, OT_CHANGES);
+        st_g[12] += rdlane(tl, OT_WIDE); st_g[13] += rdlane(tl, OT_BIG);
 #ifdef FCM_STAMP
         for (int q = 0; q < 8; ++q) p.dbgbuf[(size_t)chain * 8 + q] += stamp_acc[q];
 #endif

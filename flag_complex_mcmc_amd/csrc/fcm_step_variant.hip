@@ -34,6 +34,7 @@ extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *
 {
     size_t words = fcm_lds_words(p->maxnw);
     if (FCM_CLIQUE) words += fcm_clique_lds_words(p->chg_cap);
+    words += FCM_TALLY_LDS_WORDS;
     fcm_step_kernel<FCM_MAXT, FCM_MINW, FCM_CLIQUE, FCM_EXACT != 0>
         <<<dim3(p->nchains), dim3(WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
     return (int)hipGetLastError();
