@@ -956,7 +956,7 @@ __device__ __forceinline__ u32 mw_lds_addr_of(const void *p) { return (u32)(size
 // tallies of the one-wave kernel, u32 words in LDS: counters in words 0..9 (the first eight count events), then the OR
 // of "count entry d was non-zero after a transition" masks and of the proposals' status words
 enum { OT_ACCEPTED = 0, OT_EMPTY, OT_FLIP, OT_DMOVE, OT_CPERM, OT_CSWAP, OT_WIDE, OT_BIG, OT_SUMK, OT_CHANGES, OT_NZ, OT_STATUS };
-#define FCM_TALLY_LDS_WORDS 8u   // u64 words
+#define FCM_TALLY_LDS_WORDS 56u   // u64 words: tallies (8), then the chain's counts and bounds E[16] = {count, min, max}
 
 // Step kernel
 // ===========================================================================
@@ -983,9 +983,15 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
     const int tmax = EXACT ? MAXT : NC - 2;  // EXACT: the host picked the variant with MAXT == NC - 2
     const bool cl = lane < NC;
     // lane d holds count[d] and its bounds (zero-padded, src/util.rs:53-57)
-    u64 cnt = cl ? cnt_g[lane] : 0ull;
-    const u64 bmin = cl ? p.bmin[lane] : 0ull;
-    const u64 bmax = cl ? p.bmax[lane] : ~0ull;
+    // (in LDS, behind the tallies -- E[lane] = {count, min, max} -- and read where a proposal is decided: six registers
+    // fewer that live through the whole loop)
+    u64 *ent = smem + fcm_lds_words(p.maxnw) + (CLIQUE != 0 ? fcm_clique_lds_words(p.chg_cap) : 0u) + 8u;
+    {
+        const u64 cnt = cl ? cnt_g[lane] : 0ull;
+        const u64 bmin = cl ? p.bmin[lane] : 0ull;
+        const u64 bmax = cl ? p.bmax[lane] : ~0ull;
+        if (lane < 16) { ent[lane * 3 + 0] = cnt; ent[lane * 3 + 1] = bmin; ent[lane * 3 + 2] = bmax; }
+    }
 
     u64 sampled = st_g[0];
     // The launch's tallies live in 16 words of LDS (OT_*: one masked ds_add and one ds_or per proposal), not in a dozen
@@ -1005,7 +1011,12 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 
     // is the current state inside the bounds?  (decides whether an empty
     // transition is "accepted", src/lib.rs:186-187)
-    bool in_bounds = ballot(cl && (cnt < bmin || cnt > bmax)) == 0ull;
+    bool in_bounds;
+    {
+        wave_sync();
+        const u64 c0 = lane < 16 ? ent[lane * 3] : 0ull, mn = lane < 16 ? ent[lane * 3 + 1] : 0ull, mx = lane < 16 ? ent[lane * 3 + 2] : ~0ull;
+        in_bounds = ballot(cl && (c0 < mn || c0 > mx)) == 0ull;
+    }
 
     FcmGuard guard = {p.guard_limit, 0u};
     FCM_STAMP_DECL
@@ -1308,6 +1319,8 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     }
                 }
                 myd += wide_d;  // clique moves: evaluations that went through the wide path
+                const int el = lane < 16 ? lane : 15;   // (lanes >= NC hold {0, 0, ~0})
+                const u64 cnt = ent[el * 3], bmin = ent[el * 3 + 1], bmax = ent[el * 3 + 2];
                 const u64 ncnt = cnt + (u64)myd;
                 if (ballot(cl && myd < 0 && cnt < (u64)(-myd))) pst |= 8u;  // reference assert, src/lib.rs:65
                 // flag_count never shrinks in length (src/lib.rs:72-74)
@@ -1316,7 +1329,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                 if (ok) {
                     acc_inc = 1u;
                     in_bounds = true;
-                    cnt = ncnt;
+                    if (cl) ent[lane * 3] = ncnt;
                     if (move >= 2) {
                         if constexpr (CLIQUE != 0) {  // bits are already in place; hand over the reciprocal-pair slots
                             const CliqueLds CL = clique_carve(smem + fcm_lds_words(maxnw));
@@ -1372,8 +1385,8 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         FCM_STAMP_AT(7);                                               // (batch boundary)
     }
 
-    if (cl) cnt_g[lane] = cnt;
     wave_sync();
+    if (cl) cnt_g[lane] = ent[lane * 3];
     const u32 tl = lane < 16 ? tly[lane] : 0u;
     const u32 nzall = rdlane(tl, OT_NZ);
     const u32 nlen = nzall ? (u32)(32 - __clz((int)nzall)) : 0u;
