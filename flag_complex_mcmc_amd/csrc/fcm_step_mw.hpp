@@ -41,7 +41,7 @@
 // waves each (W = 4, 8, 16), which is what keeps the GPU busy on the per-GPU
 // shares of the 8-GPU configs (1024 and 256 chains).
 //
-// Memory ordering.  head orders LDS only (log, counts): it is passed on without waiting for the commit's global stores.
+// Memory ordering.  head orders LDS only (records, counts): it is passed on without waiting for the commit's global stores.
 // Visibility of those stores is tracked apart: wave w publishes vis[w] = "every proposal of mine below this index is
 // in memory" at the start of each proposal, after its own earlier stores have completed (s_waitcnt vmcnt(0), long
 // hidden behind the decision's tail).  snap = min over the waves of vis: every proposal below snap is visible to
@@ -186,9 +186,10 @@ __device__ __forceinline__ MwChain mw_chain_from_lds(const u32 *ctx, int lane)
     return C;
 }
 
-// What a run of a proposal leaves behind.  The wave-uniform part (MwRec) is written to the wave's staging words in LDS
-// *before* the evaluations and read back after them (SR_* words; words 0..9 are the log entry but for its ACCEPTED
-// bit): kept in SGPRs it would be live across the evaluations, where at 80 SGPRs it is spilled and reloaded.
+// What a run of a proposal leaves behind.  The wave-uniform part (MwRec) is written to the proposal's record in the ring
+// *before* the evaluations and read back after them (SR_* words; words 0..9 are what the other waves hold against their
+// reads, SR_STATE says whose record it is and whether it is staged or decided): kept in SGPRs it would be live across
+// the evaluations, where at 80 SGPRs it is spilled and reloaded.
 struct MwRec {
     u32 nonempty, is_dmove, used_wide, big_set;   // 0 / 1
     u32 wid_clr, wid_set, bit_clr, bit_set, dslot, dnew, add_k;
