@@ -570,6 +570,17 @@ def test_clique_moves_on_fixture_and_invariants(fcm, oracle):
         assert g.flagser_count() == fc and (g.undirected_edges() == und0).all() and g.nedges() == len(e)
 
 
+def test_default_mix_config_scale_oracle_twins(fcm, oracle):
+    """the reference's default move mix on the bench graph itself (ER n = 1000, p = 0.10, seed 0: 77 % clique
+    moves of about a dozen directed changes each), two chains x 500 proposals against oracle twins, tolerance 0."""
+    from flag_complex_mcmc_amd import graphs
+    n = 1000
+    e = graphs.random_with_p(n, 0.10, 0)
+    s, tw = _run_parity(fcm, oracle, n, e, n_chains=2, steps=[1, 63, 436], seed=12, weights=(0.1, 0.1, 0.6, 0.2), relaxation=0.01)
+    st = s.stats()
+    assert (st["status"] == 0).all() and (st["n_cperm"] > 200).all() and (st["n_cswap"] > 50).all() and (st["n_changes"] > 3000).all()
+
+
 def test_default_mix_config3_invariants(fcm):
     """The reference's default move mix [0.1,0.1,0.6,0.2] (src/bin/sample.rs:17) on
     the config-3 graph, 64 chains: size-independent checks."""
