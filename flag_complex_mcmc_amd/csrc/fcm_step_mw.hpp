@@ -74,6 +74,12 @@
 #ifndef MW_SLEEP_NEAR
 #define MW_SLEEP_NEAR 12  // s_sleep argument (x 64 cycles) between polls when the token is one decision away, few-records path
 #endif
+#ifndef MW_PRIO_OLDEST
+#define MW_PRIO_OLDEST 2   // s_setprio of the wave that holds its chain's oldest undecided proposal ...
+#endif
+#ifndef MW_PRIO_TOKEN
+#define MW_PRIO_TOKEN 3    // ... and of the token holder
+#endif
 #ifndef MW_K_EVLOOP
 #define MW_K_EVLOOP 0
 #endif
@@ -637,7 +643,7 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
         else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
         else __builtin_amdgcn_s_sleep(1);
     }
-    __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
+    __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
     if (!hit) {
         // (st: read after head == q was -- final)
         u64 again = ballot((st & (MS_REDONE | MS_ACCEPTED)) == (MS_REDONE | MS_ACCEPTED)) & all;
@@ -786,7 +792,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // ---- the proposal on the state as committed now.  Commits below snap are visible to every load from here on;
         // those from snap on are held against this proposal's reads before it is decided.
         // the oldest undecided proposal is what the chain's other waves end up waiting for: let it go first on its SIMD
-        if (mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == q) __builtin_amdgcn_s_setprio(2);
+        if (mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == q) __builtin_amdgcn_s_setprio(MW_PRIO_OLDEST);
         MwOut O;
         u32 *stage = ringL + (q & ring) * MW_REC_WORDS;      // this proposal's record
         MW_T(t_snap);
@@ -826,7 +832,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
                 else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
                 else __builtin_amdgcn_s_sleep(MW_SLEEP_NEAR);
             }
-            __builtin_amdgcn_s_setprio(3);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
+            __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
         }
         MW_T(t_token);
         if (hit) {
