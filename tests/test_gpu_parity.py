@@ -851,7 +851,7 @@ def test_deep_kernels_count_on_the_wide_path_when_the_bound_is_passed(fcm, oracl
     st = s.stats()
     assert (st["status"] == 0).all() and st["n_wide"].sum() > 100
     # the same inside clique moves: a changed pair's direction that passes the bound is counted on the wide path
-    s, tw = _run_parity(fcm, oracle, n, e, n_chains=2, steps=[1, 64, 400], seed=10, weights=(0.0, 0.0, 0.75, 0.25), relaxation=0.3)
+    s, tw = _run_parity(fcm, oracle, n, e, n_chains=2, steps=[1, 64, 100], seed=10, weights=(0.0, 0.0, 0.75, 0.25), relaxation=0.3)
     st = s.stats()
     assert (st["status"] == 0).all() and st["n_wide"].sum() > 100
 
