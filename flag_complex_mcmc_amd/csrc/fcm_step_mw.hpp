@@ -80,6 +80,9 @@
 #ifndef MW_PRIO_TOKEN
 #define MW_PRIO_TOKEN 3    // ... and of the token holder
 #endif
+#ifndef MW_SPIN_NEAR
+#define MW_SPIN_NEAR 1     // 1: the wave next in line (W >= 4) polls without dozing (+2 % on configs[4], neutral elsewhere)
+#endif
 #ifndef MW_K_EVLOOP
 #define MW_K_EVLOOP 0
 #endif
@@ -641,7 +644,7 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
         const u32 dist = q - h;
         if (dist >= 4u) __builtin_amdgcn_s_sleep(10);
         else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
-        else __builtin_amdgcn_s_sleep(1);
+        else if (MW_SPIN_NEAR == 0) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
     if (!hit) {
