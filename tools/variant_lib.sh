@@ -4,7 +4,7 @@
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 NAME=$1; shift
-WORK=$ROOT/tools/_stamp/$NAME
+WORK=$ROOT/tools/_stamp/$NAME   # git-ignored; travels with gpurun pushes, so only the built library is kept there (sources removed below)
 rm -rf $WORK; mkdir -p $WORK/pkg/csrc $WORK/include
 cp -r $ROOT/flag_complex_mcmc_amd/csrc/. $WORK/pkg/csrc/
 cp $ROOT/include/fcm.h $WORK/include/
