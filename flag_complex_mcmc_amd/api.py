@@ -305,12 +305,163 @@ class MCMCSampler:
         check(lib().fcm_sampler_get_edgebits(self._h, chain, out.ctypes.data_as(C.POINTER(C.c_uint8)), n.value, C.byref(n)))
         return out[: n.value]
 
+    def state(self, chain=0):
+        """The chain's `State` (MCMCSampler::state, src/lib.rs:166)."""
+        return State(self, chain)
+
     def double_slots(self, chain=0):
         n = C.c_uint64(0)
         check(lib().fcm_sampler_get_double_slots(self._h, chain, None, 0, C.byref(n)))
         out = np.zeros(max(n.value, 1), np.uint32)
         check(lib().fcm_sampler_get_double_slots(self._h, chain, out.ctypes.data_as(u32p), n.value, C.byref(n)))
         return out[: n.value]
+
+
+class Transition:
+    """`Transition { change_edges: Vec<([Node; 2], bool)> }` (src/lib.rs:200-204); `True` = add the edge."""
+
+    def __init__(self, change_edges=()):
+        self.change_edges = [((int(e[0]), int(e[1])), bool(add)) for e, add in change_edges]
+
+    def _flat(self):
+        e = np.array([c[0] for c in self.change_edges], np.uint32).reshape(-1, 2)
+        a = np.array([1 if c[1] else 0 for c in self.change_edges], np.int32)
+        return np.ascontiguousarray(e), np.ascontiguousarray(a)
+
+    @classmethod
+    def single_edge_flip(cls, state, x):
+        """Transition::single_edge_flip (src/lib.rs:292-299) on `state`'s current graph.  The reference takes an rng;
+        here the caller passes one uniform 64-bit integer `x` (the draw is DESIGN.md 3)."""
+        e = np.zeros((2, 2), np.uint32)
+        a = np.zeros(2, np.int32)
+        n = C.c_uint32(0)
+        check(lib().fcm_sampler_single_edge_flip(state._s._h, state._chain, int(x) & (2 ** 64 - 1), e.ctypes.data_as(u32p), a.ctypes.data_as(i32p), C.byref(n)))
+        return cls([((int(e[i, 0]), int(e[i, 1])), bool(a[i])) for i in range(n.value)])
+
+    def __repr__(self):
+        return "Transition(%r)" % (self.change_edges,)
+
+
+class State:
+    """The reference's `State` (src/lib.rs:29-112) of one chain of a sampler: a view, the data stays on the GPU."""
+
+    def __init__(self, sampler, chain):
+        self._s, self._chain = sampler, int(chain)
+
+    @property
+    def flag_count(self):
+        return self._s.flag_count(self._chain)
+
+    @property
+    def graph(self):
+        return self._s.graph(self._chain)
+
+    def edgeset_neighborhood(self, edges):
+        """State::edgeset_neighborhood (src/lib.rs:99-111)."""
+        e, ep = _u32(np.asarray(edges, np.uint32).reshape(-1, 2))
+        k = C.c_uint64(0)
+        check(lib().fcm_sampler_edgeset_neighborhood(self._s._h, ep, len(e), None, 0, C.byref(k)))
+        out = np.zeros(max(k.value, 1), np.uint32)
+        check(lib().fcm_sampler_edgeset_neighborhood(self._s._h, ep, len(e), out.ctypes.data_as(u32p), k.value, C.byref(k)))
+        return [int(v) for v in out[: k.value]]
+
+    def apply_transition(self, t):
+        """State::apply_transition (src/lib.rs:61-79) -> (pre, post), the reference's two count vectors."""
+        e, a = t._flat()
+        pre, post = np.zeros(_ffi.MAX_COUNTS, np.uint64), np.zeros(_ffi.MAX_COUNTS, np.uint64)
+        pl, ql = C.c_int32(0), C.c_int32(0)
+        check(lib().fcm_sampler_apply_transition(self._s._h, self._chain, e.ctypes.data_as(u32p), a.ctypes.data_as(i32p), len(a),
+                                                 pre.ctypes.data_as(u64p), C.byref(pl), post.ctypes.data_as(u64p), C.byref(ql)))
+        return [int(v) for v in pre[: pl.value]], [int(v) for v in post[: ql.value]]
+
+    def revert_transition(self, t, counters):
+        """State::revert_transition (src/lib.rs:81-95); `counters` = the (pre, post) apply_transition returned."""
+        e, a = t._flat()
+        pre, pp = _u64(list(counters[0]) + [0])
+        post, qp = _u64(list(counters[1]) + [0])
+        check(lib().fcm_sampler_revert_transition(self._s._h, self._chain, e.ctypes.data_as(u32p), a.ctypes.data_as(i32p), len(a),
+                                                  pp, len(counters[0]), qp, len(counters[1])))
+
+
+class MultiDeviceSampler:
+    """Chains sharded over several devices of ONE process: one `MCMCSampler` handle per entry of `devices`, each
+    driven by its own host thread (libfcm handles are independent; the reference's multi-chain precedent runs its
+    `State`s on OS threads, src/bin/all_cxs.rs:33-38).  Global chain c lives on shard c // ceil(C/G) and draws from
+    stream (seed, c): every result equals the single-handle run's chain for chain, whatever the device list is (a
+    device may be named twice).  The gather is host-side concatenation in global chain order."""
+
+    def __init__(self, graph, bounds, n_chains, devices, seed=0, move_weights=MOVE_DISTRIBUTION_SIMPLE,
+                 sample_distance=0, dim_cap=0):
+        from .distributed import shard_range
+        self.devices, self.ranges = [], []
+        for r, dev in enumerate(devices):
+            lo, hi = shard_range(n_chains, r, len(devices))
+            if hi > lo:
+                self.devices.append(dev)
+                self.ranges.append((lo, hi))
+        self.shards = self._parallel(lambda r: MCMCSampler(graph, bounds, n_chains=self.ranges[r][1] - self.ranges[r][0], seed=seed,
+                                                           move_weights=move_weights, sample_distance=sample_distance, dim_cap=dim_cap,
+                                                           device=self.devices[r], first_chain_id=self.ranges[r][0]))
+        self.n_chains = n_chains
+        self.bounds = bounds
+
+    def _parallel(self, fn):
+        """fn(r) for every shard, each on its own thread (ctypes releases the GIL inside libfcm)."""
+        import threading
+        n = len(self.ranges)
+        out, err = [None] * n, [None] * n
+
+        def run(r):
+            try:
+                out[r] = fn(r)
+            except BaseException as e:  # noqa: BLE001 -- carried to the caller's thread
+                err[r] = e
+        th = [threading.Thread(target=run, args=(r,)) for r in range(1, n)]
+        for t in th:
+            t.start()
+        run(0)
+        for t in th:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def step(self, n_proposals):
+        self._parallel(lambda r: self.shards[r].step(n_proposals))
+
+    def next(self):
+        self._parallel(lambda r: self.shards[r].next())
+        return self
+
+    def flag_counts(self):
+        return np.concatenate(self._parallel(lambda r: self.shards[r].flag_counts()), axis=0)
+
+    def stats(self):
+        parts = self._parallel(lambda r: self.shards[r].stats())
+        return {k: np.concatenate([p[k] for p in parts]) for k in _ffi.STAT_NAMES}
+
+    def locate(self, chain):
+        for r, (lo, hi) in enumerate(self.ranges):
+            if lo <= chain < hi:
+                return r, chain - lo
+        raise IndexError(chain)
+
+    def flag_count(self, chain=0):
+        r, c = self.locate(chain)
+        return self.shards[r].flag_count(c)
+
+    def edges(self, chain=0):
+        r, c = self.locate(chain)
+        return self.shards[r].edges(c)
+
+    def edgebits(self, chain=0):
+        r, c = self.locate(chain)
+        return self.shards[r].edgebits(c)
+
+    def double_slots(self, chain=0):
+        r, c = self.locate(chain)
+        return self.shards[r].double_slots(c)
 
 
 def initialize_new_sampler(input, target_relaxation=0.01, seed=0, sample_distance=0, simple=True,

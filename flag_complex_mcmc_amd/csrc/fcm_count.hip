@@ -152,8 +152,57 @@ __global__ __launch_bounds__(256) void fcm_broadcast_rows_kernel(uint4 *__restri
 }
 
 // ---------------------------------------------------------------------------
+// State::apply_transition as a callable (fcm_sampler_apply_transition): the induced adjacency of a vertex list
+// (the reference's Graph::subgraph, src/lib.rs:63,71) read off one chain's bitmap, and set_edge on it (:68-70).
+// Neither is on the stepping path.
+// ---------------------------------------------------------------------------
+// out[i][w] (u32 words, nlw per row): bit j of the row = list[i] -> list[j].  One wave per row.
+__global__ __launch_bounds__(WAVE) void fcm_gather_sub_kernel(const u32 *__restrict__ rows, u32 stride32, const u32 *__restrict__ list, u32 nl,
+                                                              u32 nlw, u32 *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const u32 i = blockIdx.x;
+    if (i >= nl) return;
+    const u32 *row = rows + (size_t)list[i] * stride32;
+    for (u32 j0 = 0; j0 < nl; j0 += WAVE) {
+        const u32 j = j0 + (u32)lane;
+        bool bit = false;
+        if (j < nl && j != i) { const u32 v = list[j]; bit = (row[v >> 5] >> (v & 31u)) & 1u; }
+        const u64 m = ballot(bit);
+        if (lane == 0) {
+            out[(size_t)i * nlw + (j0 >> 5)] = (u32)m;
+            if ((j0 >> 5) + 1u < nlw) out[(size_t)i * nlw + (j0 >> 5) + 1u] = (u32)(m >> 32);
+        }
+    }
+}
+// changes[c] = {from, to, present}: applied in order by one thread (an edge may be named twice)
+__global__ void fcm_set_edges_kernel(u32 *rows, u32 stride32, const u32 *__restrict__ changes, u32 nchanges)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (u32 c = 0; c < nchanges; ++c) {
+        const u32 a = changes[3 * c], b = changes[3 * c + 1];
+        u32 *w = rows + (size_t)a * stride32 + (b >> 5);
+        const u32 bit = 1u << (b & 31u);
+        *w = changes[3 * c + 2] ? (*w | bit) : (*w & ~bit);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
+extern "C" int fcm_launch_gather_sub(const uint32_t *rows, uint32_t stride32, const uint32_t *list, uint32_t nl, uint32_t nlw, uint32_t *out, void *stream)
+{
+    if (nl == 0) return 0;
+    hipLaunchKernelGGL(fcm_gather_sub_kernel, dim3(nl), dim3(WAVE), 0, (hipStream_t)stream, rows, stride32, list, nl, nlw, out);
+    return (int)hipGetLastError();
+}
+extern "C" int fcm_launch_set_edges(uint32_t *rows, uint32_t stride32, const uint32_t *changes, uint32_t nchanges, void *stream)
+{
+    if (nchanges == 0) return 0;
+    hipLaunchKernelGGL(fcm_set_edges_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rows, stride32, changes, nchanges);
+    return (int)hipGetLastError();
+}
+
 typedef int (*fcm_step_launcher)(const FcmStepParams *, void *);
 #define FCM_DECL_STEP(tag) int fcm_launch_step_##tag##_0(const FcmStepParams *, void *); int fcm_launch_step_##tag##_1(const FcmStepParams *, void *);
 extern "C" {

@@ -74,6 +74,8 @@ extern "C" {
 int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, void *stream);
 int fcm_launch_count(const FcmCountParams *p, void *stream);
 int fcm_launch_count_xw(const FcmCountParams *p, uint32_t nflagged, void *stream);   // the edges of xlist, one wave each
+int fcm_launch_gather_sub(const uint32_t *rows, uint32_t stride32, const uint32_t *list, uint32_t nl, uint32_t nlw, uint32_t *out, void *stream);
+int fcm_launch_set_edges(uint32_t *rows, uint32_t stride32, const uint32_t *changes, uint32_t nchanges, void *stream);
 int fcm_launch_broadcast_rows(uint32_t *rows, const uint32_t *base, uint64_t words_per_chain, uint32_t nchains, void *stream);
 #ifdef __cplusplus
 }

@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <exception>
+#include <mutex>
 #include <new>
 #include <sstream>
 #include <stdexcept>
@@ -63,6 +65,7 @@ static int guard_fail()
 }
 #define FCM_CATCH catch (...) { return guard_fail(); }
 #define FCM_CATCH_PTR catch (...) { (void)guard_fail(); return nullptr; }
+#define FCM_CATCH_FALSE catch (...) { (void)guard_fail(); return 0; }   // entry points whose int result is a boolean
 
 extern "C" const char *fcm_last_error(void) { return g_err; }
 extern "C" const char *fcm_version(void) { return "fcm-amd 0.1 (gfx950)"; }
@@ -165,7 +168,7 @@ extern "C" int fcm_graph_has_edge(const fcm_graph *g, fcm_node a, fcm_node b)
 try {
     if (!g || a >= g->n || b >= g->n) return 0;
     return g->has(a, b) ? 1 : 0;
-} FCM_CATCH
+} FCM_CATCH_FALSE
 
 extern "C" int fcm_graph_set_edge(fcm_graph *g, fcm_node a, fcm_node b, int present)
 try {
@@ -557,7 +560,7 @@ extern "C" int fcm_bounds_check(const fcm_bounds *b, const uint64_t *flag_count,
 try {
     if (!b || !flag_count) return 0;
     return all_le(b->flag_count_min, b->min_len, flag_count, len) && all_le(flag_count, len, b->flag_count_max, b->max_len);
-} FCM_CATCH
+} FCM_CATCH_FALSE
 
 extern "C" uint64_t fcm_default_sample_distance(uint64_t nedges)
 {
@@ -692,6 +695,12 @@ struct fcm_sampler {
     // device buffers
     DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats, d_clq, d_clq_pairs, d_efirst, d_slot_of, d_dbg, d_xw;
     bool clique_moves = false;
+    // host copies of the static tables, fetched on the first use of the State API (apply/revert/edgeset_neighborhood)
+    std::vector<FcmEdgeEntry> h_etab;
+    std::vector<uint32_t> h_nb;
+    bool h_tables = false;
+    DevBuf d_tr_list, d_tr_out, d_tr_chg;   // scratch of that API
+    size_t tr_list_cap = 0, tr_out_cap = 0, tr_chg_cap = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -769,11 +778,27 @@ try {
         }
         const unsigned hw = std::thread::hardware_concurrency();
         const unsigned nthreads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1, 16), U / 4096 + 1));
+        // Shares 0 .. nthreads-1 of `fn`, one host thread each.  A thread that cannot be started (std::system_error at the
+        // thread limit, bad_alloc) must not leave joinable threads behind -- the vector's destructor would call
+        // std::terminate, across the C boundary: the shares without a thread run inline, and an exception out of a share
+        // itself is carried to this thread and rethrown once every thread has been joined.
         auto run_parallel = [&](auto &&fn) {
             std::vector<std::thread> th;
-            for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(fn, t);
-            fn(0u);
+            std::exception_ptr err;
+            std::mutex err_mu;
+            auto guarded = [&](unsigned t) {
+                try { fn(t); }
+                catch (...) { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
+            };
+            unsigned started = 1;
+            try {
+                th.reserve(nthreads);
+                for (; started < nthreads; ++started) th.emplace_back(guarded, started);
+            } catch (...) { /* the shares from `started` on run inline below */ }
+            guarded(0u);
+            for (unsigned t = started; t < nthreads; ++t) guarded(t);
             for (auto &x : th) x.join();
+            if (err) std::rethrow_exception(err);
         };
         run_parallel([&](unsigned t) {
             for (uint64_t v = (uint64_t)g->n * t / nthreads; v < (uint64_t)g->n * (t + 1) / nthreads; ++v)
@@ -1218,6 +1243,301 @@ extern "C" int fcm_sampler_get_bounds(const fcm_sampler *s, fcm_bounds *out)
 try {
     if (!s || !out) return fail(FCM_ERR_INVALID, "NULL argument");
     *out = s->bounds;
+    return FCM_OK;
+} FCM_CATCH
+
+// ---------------------------------------------------------------------------
+// State API on one chain: edgeset_neighborhood (src/lib.rs:99-111), apply_transition (:61-79), revert_transition
+// (:81-95), Transition::single_edge_flip (:292-299).  What the reference's search tools call between proposals
+// (src/bin/seo_search_counterexample.rs:51-89, seo_bt_flip_only_once.rs:65-69, all_cxs.rs:54-86).  (pre, post) are the
+// reference's own vectors -- flagser_count of the induced subgraph on the edge set's neighbourhood before and after --
+// counted by the HIP counting kernel; callers look at their lengths as well as at post[2] - pre[2].
+// Host-orchestrated, a few launches and small copies per call: not the stepping path.
+// ---------------------------------------------------------------------------
+static int ensure_host_tables(fcm_sampler *s)
+{
+    if (s->h_tables) return FCM_OK;
+    const size_t U = s->ue.size() / 2;
+    s->h_etab.resize(U);
+    if (U) HIP_TRY(hipMemcpy(s->h_etab.data(), s->d_etab.p, U * sizeof(FcmEdgeEntry), hipMemcpyDeviceToHost));
+    size_t total = 0;
+    if (U) total = (size_t)s->h_etab[U - 1].nb_off + s->h_etab[U - 1].k;
+    s->h_nb.resize(total);
+    if (total) HIP_TRY(hipMemcpy(s->h_nb.data(), s->d_nb.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    s->h_tables = true;
+    return FCM_OK;
+}
+
+// etab index of the adjacent pair {a, b}, or -1 (the reference indexes a HashMap with it: a missing key panics)
+static int64_t pair_index(const fcm_sampler *s, uint32_t a, uint32_t b)
+{
+    const uint32_t big = std::max(a, b), small = std::min(a, b);
+    size_t lo = 0, hi = s->ue.size() / 2;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        const uint32_t mb = s->ue[2 * mid], ms = s->ue[2 * mid + 1];
+        if (mb < big || (mb == big && ms < small)) lo = mid + 1; else hi = mid;
+    }
+    if (lo < s->ue.size() / 2 && s->ue[2 * lo] == big && s->ue[2 * lo + 1] == small) return (int64_t)lo;
+    return -1;
+}
+
+static int check_transition_args(const fcm_sampler *s, uint32_t chain, const fcm_node *edges, const int32_t *add, uint32_t n)
+{
+    if (!s) return fail(FCM_ERR_INVALID, "sampler is NULL");
+    if (chain >= s->params.nchains) return fail(FCM_ERR_INVALID, "chain %u out of range", chain);
+    if (n && (!edges || !add)) return fail(FCM_ERR_INVALID, "NULL argument");
+    if (n > 4096) return fail(FCM_ERR_UNSUPPORTED, "%u change edges; at most 4096 per transition", n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t a = edges[2 * i], b = edges[2 * i + 1];
+        if (a >= s->n || b >= s->n || a == b) return fail(FCM_ERR_INVALID, "change edge %u = (%u,%u) out of range or a loop", i, a, b);
+        if (pair_index(s, a, b) < 0)
+            return fail(FCM_ERR_PANIC, "change edge %u = (%u,%u): the pair is not adjacent in pr(G); the reference indexes edge_neighborhood with it (src/lib.rs:104)", i, a, b);
+    }
+    return FCM_OK;
+}
+
+static int edgeset_neighborhood(fcm_sampler *s, const fcm_node *edges, uint32_t n, std::vector<uint32_t> &out)
+{
+    int rc = ensure_host_tables(s);
+    if (rc) return rc;
+    out.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        const int64_t e = pair_index(s, edges[2 * i], edges[2 * i + 1]);
+        if (e < 0) return fail(FCM_ERR_PANIC, "edge (%u,%u) is not in edge_neighborhood (src/lib.rs:104)", edges[2 * i], edges[2 * i + 1]);
+        const FcmEdgeEntry &t = s->h_etab[(size_t)e];
+        out.insert(out.end(), s->h_nb.begin() + t.nb_off, s->h_nb.begin() + t.nb_off + t.k);
+        out.push_back(edges[2 * i]);
+        out.push_back(edges[2 * i + 1]);
+    }
+    std::sort(out.begin(), out.end());                       // sort_unstable, dedup (:108-109)
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_edgeset_neighborhood(fcm_sampler *s, const fcm_node *edges, uint32_t n, fcm_node *out, uint64_t cap, uint64_t *k)
+try {
+    if (!s || (n && !edges)) return fail(FCM_ERR_INVALID, "NULL argument");
+    int rc = use_device(s->device);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n; ++i)
+        if (edges[2 * i] >= s->n || edges[2 * i + 1] >= s->n) return fail(FCM_ERR_INVALID, "edge %u out of range", i);
+    std::vector<uint32_t> nb;
+    if ((rc = edgeset_neighborhood(s, edges, n, nb))) return rc;
+    if (k) *k = nb.size();
+    if (out) memcpy(out, nb.data(), sizeof(uint32_t) * (size_t)std::min<uint64_t>(cap, nb.size()));
+    return FCM_OK;
+} FCM_CATCH
+
+// induced adjacency of `list` in the chain's current graph: sub[i * nlw + w], bit j = list[i] -> list[j]
+static int gather_sub(fcm_sampler *s, uint32_t chain, const std::vector<uint32_t> &list, std::vector<uint32_t> &sub, uint32_t &nlw)
+{
+    const uint32_t nl = (uint32_t)list.size();
+    nlw = (nl + 63) / 64 * 2;
+    sub.assign((size_t)nl * nlw, 0u);
+    if (nl == 0) return FCM_OK;
+    int rc;
+    if (s->tr_list_cap < nl) { DevBuf nb_; if ((rc = nb_.alloc((size_t)nl * 4))) return rc; std::swap(s->d_tr_list.p, nb_.p); s->tr_list_cap = nl; }
+    if (s->tr_out_cap < sub.size()) { DevBuf nb_; if ((rc = nb_.alloc(sub.size() * 4))) return rc; std::swap(s->d_tr_out.p, nb_.p); s->tr_out_cap = sub.size(); }
+    HIP_TRY(hipMemcpyAsync(s->d_tr_list.p, list.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s->stream));
+    const uint32_t *rows = s->d_rows.as<uint32_t>() + (size_t)chain * s->params.rows_per_chain;
+    int lrc = fcm_launch_gather_sub(rows, s->stride32, s->d_tr_list.as<uint32_t>(), nl, nlw, s->d_tr_out.as<uint32_t>(), s->stream);
+    if (lrc) return fail(FCM_ERR_HIP, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    HIP_TRY(hipMemcpyAsync(sub.data(), s->d_tr_out.p, sub.size() * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return FCM_OK;
+}
+
+// flagser_count of the graph on `nl` vertices whose adjacency is `sub` (as gather_sub makes it)
+static int count_sub(const fcm_sampler *s, const std::vector<uint32_t> &sub, uint32_t nl, uint32_t nlw, uint64_t counts[FCM_MAX_COUNTS], int *len)
+{
+    const uint32_t st = stride_for(nl);
+    std::vector<uint32_t> rows((size_t)nl * st, 0u), edges;
+    for (uint32_t i = 0; i < nl; ++i)
+        for (uint32_t w = 0; w < nlw; ++w) {
+            uint32_t x = sub[(size_t)i * nlw + w];
+            rows[(size_t)i * st + w] = x;
+            while (x) { edges.push_back(i); edges.push_back(w * 32 + (uint32_t)__builtin_ctz(x)); x &= x - 1; }
+        }
+    return device_count(rows.data(), nl, st, edges, s->device, counts, len);
+}
+
+static inline bool sub_has(const std::vector<uint32_t> &sub, uint32_t nlw, uint32_t i, uint32_t j) { return (sub[(size_t)i * nlw + (j >> 5)] >> (j & 31)) & 1u; }
+static inline void sub_set(std::vector<uint32_t> &sub, uint32_t nlw, uint32_t i, uint32_t j, bool present)
+{
+    uint32_t &w = sub[(size_t)i * nlw + (j >> 5)];
+    const uint32_t b = 1u << (j & 31);
+    w = present ? (w | b) : (w & ~b);
+}
+
+// The chain's reciprocal-pair slot list after set_edge calls: the pairs (ascending id) that stopped being reciprocal
+// hand their slots to the pairs that became reciprocal, in order (the rule of the clique moves).  The
+// kernels draw double-edge moves over a fixed number D of slots, so a transition that changes the number of
+// reciprocal pairs is refused before anything is written.
+struct SlotPlan { std::vector<uint32_t> lost, gained; };
+static int plan_slots(const fcm_sampler *s, const std::vector<uint32_t> &list, const std::vector<uint32_t> &before, const std::vector<uint32_t> &after,
+                      uint32_t nlw, const fcm_node *edges, uint32_t n, SlotPlan &plan)
+{
+    auto idx = [&](uint32_t v) { return (uint32_t)(std::lower_bound(list.begin(), list.end(), v) - list.begin()); };
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < n; ++i) ids.push_back((uint32_t)pair_index(s, edges[2 * i], edges[2 * i + 1]));
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    for (uint32_t e : ids) {
+        const uint32_t ia = idx(s->ue[2 * (size_t)e]), ib = idx(s->ue[2 * (size_t)e + 1]);
+        const bool rb = sub_has(before, nlw, ia, ib) && sub_has(before, nlw, ib, ia), ra = sub_has(after, nlw, ia, ib) && sub_has(after, nlw, ib, ia);
+        if (rb && !ra) plan.lost.push_back(e);
+        if (ra && !rb) plan.gained.push_back(e);
+        if (!sub_has(after, nlw, ia, ib) && !sub_has(after, nlw, ib, ia))
+            return fail(FCM_ERR_UNSUPPORTED, "the transition leaves the pair (%u,%u) without an edge: pr(G), and with it the static tables, would change",
+                        s->ue[2 * (size_t)e], s->ue[2 * (size_t)e + 1]);
+    }
+    if (plan.lost.size() != plan.gained.size())
+        return fail(FCM_ERR_UNSUPPORTED, "the transition changes the number of reciprocal pairs (%zu lost, %zu gained); the sampler draws over a fixed number of them",
+                    plan.lost.size(), plan.gained.size());
+    return FCM_OK;
+}
+static int commit_slots(fcm_sampler *s, uint32_t chain, const SlotPlan &plan)
+{
+    if (plan.lost.empty()) return FCM_OK;
+    const uint64_t D = s->params.D;
+    std::vector<uint32_t> dbl((size_t)D);
+    uint32_t *d_dbl = s->d_dbl.as<uint32_t>() + (size_t)chain * s->params.dbl_stride;
+    HIP_TRY(hipMemcpy(dbl.data(), d_dbl, (size_t)D * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < plan.lost.size(); ++i) {
+        const auto it = std::find(dbl.begin(), dbl.end(), plan.lost[i]);
+        if (it == dbl.end()) return fail(FCM_ERR_INTERNAL, "chain %u: reciprocal pair %u is not in the slot list", chain, plan.lost[i]);
+        const uint32_t slot = (uint32_t)(it - dbl.begin()), ge = plan.gained[i];
+        *it = ge;
+        HIP_TRY(hipMemcpy(d_dbl + slot, &ge, 4, hipMemcpyHostToDevice));
+        if (s->clique_moves) {
+            uint32_t *so = s->d_slot_of.as<uint32_t>() + (size_t)chain * s->params.U;
+            const uint32_t none = 0xFFFFFFFFu;
+            HIP_TRY(hipMemcpy(so + plan.lost[i], &none, 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(so + ge, &slot, 4, hipMemcpyHostToDevice));
+        }
+    }
+    return FCM_OK;
+}
+
+static int set_edges_on_device(fcm_sampler *s, uint32_t chain, const fcm_node *edges, const int32_t *add, uint32_t n, bool invert)
+{
+    if (n == 0) return FCM_OK;
+    std::vector<uint32_t> chg((size_t)n * 3);
+    for (uint32_t i = 0; i < n; ++i) { chg[3 * i] = edges[2 * i]; chg[3 * i + 1] = edges[2 * i + 1]; chg[3 * i + 2] = ((add[i] != 0) != invert) ? 1u : 0u; }
+    int rc;
+    if (s->tr_chg_cap < chg.size()) { DevBuf nb_; if ((rc = nb_.alloc(chg.size() * 4))) return rc; std::swap(s->d_tr_chg.p, nb_.p); s->tr_chg_cap = chg.size(); }
+    HIP_TRY(hipMemcpyAsync(s->d_tr_chg.p, chg.data(), chg.size() * 4, hipMemcpyHostToDevice, s->stream));
+    uint32_t *rows = s->d_rows.as<uint32_t>() + (size_t)chain * s->params.rows_per_chain;
+    int lrc = fcm_launch_set_edges(rows, s->stride32, s->d_tr_chg.as<uint32_t>(), n, s->stream);
+    if (lrc) return fail(FCM_ERR_HIP, "set_edge launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return FCM_OK;
+}
+
+// flag_count -= sub; (resize) += add -- src/lib.rs:64-67,72-77 and :85-94.  The reference asserts while it subtracts; here
+// the check comes first and a failing one changes nothing.
+static int update_counts(fcm_sampler *s, uint32_t chain, const uint64_t *sub, int sub_len, const uint64_t *addv, int add_len)
+{
+    const int nc = s->params.ncounts;
+    uint64_t c[FCM_MAX_COUNTS];
+    uint64_t *d_c = s->d_counts.as<uint64_t>() + (size_t)chain * FCM_MAX_COUNTS;
+    uint64_t *d_len = s->d_stats.as<uint64_t>() + (size_t)chain * FCM_NSTATS + FCM_STAT_COUNT_LEN;
+    uint64_t len = 0;
+    HIP_TRY(hipMemcpy(c, d_c, sizeof c, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&len, d_len, 8, hipMemcpyDeviceToHost));
+    for (int d = 0; d < sub_len && d < nc && d < (int)len; ++d)      // zip: up to the shorter of the two
+        if (c[d] < sub[d]) return fail(FCM_ERR_PANIC, "flag_count[%d] = %llu < %llu: the reference's assert!(*s >= *p) fires (src/lib.rs:65,86)", d,
+                                       (unsigned long long)c[d], (unsigned long long)sub[d]);
+    for (int d = 0; d < sub_len && d < nc && d < (int)len; ++d) c[d] -= sub[d];
+    if ((uint64_t)std::min(add_len, nc) > len) len = (uint64_t)std::min(add_len, nc);   // flag_count.resize(post.len(), 0): never shrinks
+    for (int d = 0; d < add_len && d < nc; ++d) c[d] += addv[d];
+    HIP_TRY(hipMemcpy(d_c, c, sizeof c, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_len, &len, 8, hipMemcpyHostToDevice));
+    return FCM_OK;
+}
+
+extern "C" int fcm_sampler_apply_transition(fcm_sampler *s, uint32_t chain, const fcm_node *edges, const int32_t *add, uint32_t n,
+                                            uint64_t *pre, int32_t *pre_len, uint64_t *post, int32_t *post_len)
+try {
+    int rc = check_transition_args(s, chain, edges, add, n);
+    if (rc) return rc;
+    if (!pre || !pre_len || !post || !post_len) return fail(FCM_ERR_INVALID, "NULL argument");
+    if ((rc = fcm_sampler_sync(s))) return rc;
+    std::vector<uint32_t> list, before, after;
+    if ((rc = edgeset_neighborhood(s, edges, n, list))) return rc;               // :62
+    uint32_t nlw = 0;
+    if ((rc = gather_sub(s, chain, list, before, nlw))) return rc;               // Graph::subgraph, :63
+    uint64_t cpre[FCM_MAX_COUNTS], cpost[FCM_MAX_COUNTS];
+    int lpre = 0, lpost = 0;
+    if ((rc = count_sub(s, before, (uint32_t)list.size(), nlw, cpre, &lpre))) return rc;
+    after = before;
+    auto idx = [&](uint32_t v) { return (uint32_t)(std::lower_bound(list.begin(), list.end(), v) - list.begin()); };
+    for (uint32_t i = 0; i < n; ++i) sub_set(after, nlw, idx(edges[2 * i]), idx(edges[2 * i + 1]), add[i] != 0);   // set_edge, :68-70
+    if ((rc = count_sub(s, after, (uint32_t)list.size(), nlw, cpost, &lpost))) return rc;                            // :71
+    SlotPlan plan;
+    if ((rc = plan_slots(s, list, before, after, nlw, edges, n, plan))) return rc;
+    if ((rc = update_counts(s, chain, cpre, lpre, cpost, lpost))) return rc;     // :64-67, :72-77
+    if ((rc = set_edges_on_device(s, chain, edges, add, n, false))) return rc;
+    if ((rc = commit_slots(s, chain, plan))) return rc;
+    for (int d = 0; d < FCM_MAX_COUNTS; ++d) { pre[d] = d < lpre ? cpre[d] : 0; post[d] = d < lpost ? cpost[d] : 0; }
+    *pre_len = lpre; *post_len = lpost;
+    return FCM_OK;
+} FCM_CATCH
+
+extern "C" int fcm_sampler_revert_transition(fcm_sampler *s, uint32_t chain, const fcm_node *edges, const int32_t *add, uint32_t n,
+                                             const uint64_t *pre, int32_t pre_len, const uint64_t *post, int32_t post_len)
+try {
+    int rc = check_transition_args(s, chain, edges, add, n);
+    if (rc) return rc;
+    if ((pre_len && !pre) || (post_len && !post) || pre_len < 0 || post_len < 0 || pre_len > FCM_MAX_COUNTS || post_len > FCM_MAX_COUNTS)
+        return fail(FCM_ERR_INVALID, "bad (pre, post)");
+    if ((rc = fcm_sampler_sync(s))) return rc;
+    // the pairs' bits now and after set_edge(a, b, !add) (:82-84): for the slot list only -- a revert counts nothing
+    std::vector<uint32_t> list, before, after;
+    for (uint32_t i = 0; i < n; ++i) { list.push_back(edges[2 * i]); list.push_back(edges[2 * i + 1]); }
+    std::sort(list.begin(), list.end());
+    list.erase(std::unique(list.begin(), list.end()), list.end());
+    uint32_t nlw = 0;
+    if ((rc = gather_sub(s, chain, list, before, nlw))) return rc;
+    after = before;
+    auto idx = [&](uint32_t v) { return (uint32_t)(std::lower_bound(list.begin(), list.end(), v) - list.begin()); };
+    for (uint32_t i = 0; i < n; ++i) sub_set(after, nlw, idx(edges[2 * i]), idx(edges[2 * i + 1]), add[i] == 0);
+    SlotPlan plan;
+    if ((rc = plan_slots(s, list, before, after, nlw, edges, n, plan))) return rc;
+    if ((rc = update_counts(s, chain, post, post_len, pre, pre_len))) return rc;   // :85-94
+    if ((rc = set_edges_on_device(s, chain, edges, add, n, true))) return rc;
+    return commit_slots(s, chain, plan);
+} FCM_CATCH
+
+// Transition::single_edge_flip (src/lib.rs:292-299) on the chain's current graph.  The reference draws a directed edge
+// with the caller's rng; here the caller hands over one uniform 64-bit number x and the draw is the sampler's own
+// (DESIGN.md 3): r = mulhi64(x, U + D) names a directed edge; a reciprocal pair gives the empty transition.
+extern "C" int fcm_sampler_single_edge_flip(fcm_sampler *s, uint32_t chain, uint64_t x, fcm_node *edges /* [2][2] */, int32_t *add /* [2] */, uint32_t *n)
+try {
+    if (!s || !edges || !add || !n) return fail(FCM_ERR_INVALID, "NULL argument");
+    if (chain >= s->params.nchains) return fail(FCM_ERR_INVALID, "chain %u out of range", chain);
+    int rc = fcm_sampler_sync(s);
+    if (rc) return rc;
+    *n = 0;
+    const uint64_t U = s->params.U, M = U + s->params.D;
+    if (M == 0) return FCM_OK;                                                  // sample_edge -> None (:293)
+    const uint64_t r = (uint64_t)(((unsigned __int128)x * M) >> 64);
+    if (r >= U) return FCM_OK;                                                  // the second direction of a reciprocal pair: reverse present (:294)
+    const uint32_t big = s->ue[2 * (size_t)r], small = s->ue[2 * (size_t)r + 1];
+    const uint32_t *rows = s->d_rows.as<uint32_t>() + (size_t)chain * s->params.rows_per_chain;
+    uint32_t wbs = 0, wsb = 0;
+    HIP_TRY(hipMemcpy(&wbs, rows + (size_t)big * s->stride32 + (small >> 5), 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&wsb, rows + (size_t)small * s->stride32 + (big >> 5), 4, hipMemcpyDeviceToHost));
+    const bool bs = (wbs >> (small & 31)) & 1u, sb = (wsb >> (big & 31)) & 1u;
+    if (bs == sb) {
+        if (!bs) return fail(FCM_ERR_INTERNAL, "chain %u: pair (%u,%u) is adjacent in the table and absent from the bitmap", chain, big, small);
+        return FCM_OK;                                                          // reciprocal: empty transition (:297-298)
+    }
+    const uint32_t from = bs ? big : small, to = bs ? small : big;
+    edges[0] = from; edges[1] = to; add[0] = 0;                                 // ([from,to], false), ([to,from], true) (:295)
+    edges[2] = to; edges[3] = from; add[1] = 1;
+    *n = 2;
     return FCM_OK;
 } FCM_CATCH
 

@@ -58,8 +58,8 @@
 #define MW_MINW 8
 #endif
 // Code-shape knobs.  They change nothing in what the kernel computes; they decide whether hipcc finds a clean
-// allocation at 64 VGPRs / 80 SGPRs for a given variant (tools/scratch_census.sh; the Makefile sets them per variant
-// from tools/tune_knobs.sh).  ZERO: the count registers are zeroed by instructions of their own.  LANE: the lane id
+// allocation at 64 VGPRs / 80 SGPRs for a given variant (tools/scratch_census.sh; the defaults below are what
+// tools/tune_knobs.sh found clean for every variant; `make EXTRA=-DMW_K_..=..` overrides them for all variants).  ZERO: the count registers are zeroed by instructions of their own.  LANE: the lane id
 // is made opaque per proposal, so that comparisons with it are not hoisted out of the loop.  EVLOOP: the two
 // evaluations of a proposal run as a loop over one inlined evaluator (1) or as two inlined copies (0).
 #ifndef MW_K_ZERO
@@ -118,8 +118,10 @@ enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SE
 #endif
 #define MW_TALLY_WAVE_OFF (128u + (MW_TBL_N * MW_TBL_WORDS) / 2u)
 #define MW_WAVE_WORDS (MW_TALLY_WAVE_OFF + 9u)
+#define SR_WORDS_C 14u   // = SR_WORDS (the enum below)
 #define MW_REC_WORDS 14u                                  // a record: SR_* words, u32
 #define MW_RING_WORDS(W) (4u * (W) * (MW_REC_WORDS / 2u))   // u64 words
+static_assert(MW_REC_WORDS % 2u == 0u && SR_WORDS_C == MW_REC_WORDS, "a record is a whole number of 64-bit words (mw_stage stores it as such)");
 __host__ __device__ constexpr inline unsigned fcm_mw_lds_words(int NW, int W)
 {
     return MW_SHARED_WORDS + MW_RING_WORDS((unsigned)W) + (unsigned)W * MW_WAVE_WORDS + fcm_lds_words(NW < 2 ? 2 : NW);
@@ -205,6 +207,7 @@ struct MwRec {
     u32 id1, big1, small1, id2, big2, small2, cx0, cx1, sus;
 };
 enum { SR_FLAGS = 0, SR_BIG1, SR_SMALL1, SR_ID1, SR_BIG2, SR_SMALL2, SR_ID2, SR_DSLOT, SR_WCLR, SR_WSET, SR_CX0, SR_CX1, SR_SUS, SR_STATE, SR_WORDS };
+static_assert(SR_WORDS == SR_WORDS_C && SR_STATE == SR_SUS + 1 && SR_SUS % 2 == 0, "record layout");
 // SR_FLAGS: nonempty<<0 | dmove<<1 | used_wide<<2 | big_set<<3 | add_k<<8 (12 bits) | clr bit index<<20 | set bit index<<25
 #define SRF_NONEMPTY 1u
 #define SRF_DMOVE 2u
@@ -222,10 +225,13 @@ __device__ __forceinline__ void mw_stage(u32 *stage, const MwRec &R, int lane, u
     if (lane == 0) {
         const u32 fl = R.nonempty | (R.is_dmove << 1) | (R.used_wide << 2) | (R.big_set << 3) | ((R.add_k & 0xFFFu) << 8)
                        | (R.bit_clr << 20) | (R.bit_set << 25);   // (bit indices, 0..31)
-        *(uint4 *)(stage + 0) = make_uint4(fl, R.big1, R.small1, R.id1);
-        *(uint4 *)(stage + 4) = make_uint4(R.big2, R.small2, R.id2, R.dslot);
-        *(uint4 *)(stage + 8) = make_uint4(R.wid_clr, R.wid_set, R.cx0, R.cx1);
-        *(uint2 *)(stage + SR_SUS) = make_uint2(R.sus, state);
+        // (64-bit stores: the ring starts at an 8-byte boundary and a record is 56 bytes, so a record is 8-byte aligned only;
+        //  hipcc pairs them into ds_write2_b64, which asks for no more)
+        uint2 *st2 = (uint2 *)stage;
+        st2[0] = make_uint2(fl, R.big1); st2[1] = make_uint2(R.small1, R.id1);
+        st2[2] = make_uint2(R.big2, R.small2); st2[3] = make_uint2(R.id2, R.dslot);
+        st2[4] = make_uint2(R.wid_clr, R.wid_set); st2[5] = make_uint2(R.cx0, R.cx1);
+        st2[6] = make_uint2(R.sus, state);
     }
     wave_sync();
 }

@@ -129,7 +129,9 @@ __device__ __forceinline__ void xw_dfs(const XWide &X, const XCls &c, int tmax, 
             rem = cand & (ph2 == 0 ? c.P : (ph2 == 1 ? c.M : c.S));
             const int pc = wave_sum_i32(__popcll(rem));
             if (lane == level + 1) acc += (long long)sign * pc;
-            if (!(level + 2 <= tmax)) rem = 0ull;
+            // (with `overflow` given -- the counter's second pass -- the children of the last tracked level are still looked at,
+            //  as wide_dfs<DETECT> does: a non-empty child set there means simplices beyond the tracked dimensions exist)
+            if (!(overflow != nullptr || level + 2 <= tmax)) rem = 0ull;
             continue;
         }
         // next child x of class ph2: the lowest set bit of the lowest non-empty word

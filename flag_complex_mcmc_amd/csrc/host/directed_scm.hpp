@@ -10,6 +10,9 @@
 //   io::read_flag_file / save_flag_file      fcm::io::...          (src/io.rs:18-48)
 //   io::save_state / load_state              MCMCSampler::save_state / load_state (src/io.rs:51-62)
 //   io::BitOutput                            fcm::io::BitOutput    (src/io.rs:128-212)
+//   Transition{change_edges}                 fcm::Transition       (src/lib.rs:200-204, 292-299)
+//   State::{apply,revert}_transition, ...    fcm::State            (src/lib.rs:61-111), a view of one chain
+//   (one process, many OS threads: all_cxs.rs:33-38)   fcm::MultiDeviceSampler: one handle per device, one host thread each
 //
 // Rust panics (unwrap/expect/assert!) become fcm::Error exceptions.
 #pragma once
@@ -18,6 +21,10 @@
 #include <stdexcept>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
+#include <exception>
+#include <memory>
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -125,6 +132,8 @@ struct Bounds {
     }
 };
 
+class State;
+
 /// A batch of independent MCMCSampler chains on one GPU.
 class MCMCSampler {
 public:
@@ -204,11 +213,184 @@ public:
         return {(size_t)n, MCMCSampler(h)};
     }
     const fcm_sampler_info &info() const { return info_; }
+    fcm_sampler *raw() const { return h_; }
+    State state(uint32_t chain);   // the chain's `State` (MCMCSampler::state, src/lib.rs:166)
 
 private:
     void refresh() { check(fcm_sampler_get_info(h_, &info_)); }
     fcm_sampler *h_ = nullptr;
     fcm_sampler_info info_{};
+};
+
+/// `Transition { change_edges: Vec<([Node; 2], bool)> }` (src/lib.rs:200-204); true = add the edge
+struct Transition {
+    std::vector<std::pair<Edge, bool>> change_edges;
+    void flat(std::vector<fcm_node> &e, std::vector<int32_t> &a) const
+    {
+        e.clear(); a.clear();
+        for (const auto &c : change_edges) { e.push_back(c.first.first); e.push_back(c.first.second); a.push_back(c.second ? 1 : 0); }
+    }
+};
+using Counters = std::pair<std::vector<size_t>, std::vector<size_t>>;   // (pre, post) of apply_transition
+
+/// The reference's `State` (src/lib.rs:29-112) of one chain of a sampler: a view, the data stays on the GPU.
+class State {
+public:
+    State(MCMCSampler &s, uint32_t chain) : s_(s), chain_(chain) {}
+    std::vector<size_t> flag_count() { return s_.flag_counts()[chain_]; }
+    Graph graph() { return s_.graph(chain_); }
+    /// State::edgeset_neighborhood (src/lib.rs:99-111)
+    std::vector<Node> edgeset_neighborhood(const std::vector<Edge> &edges)
+    {
+        std::vector<fcm_node> flat;
+        for (const auto &e : edges) { flat.push_back(e.first); flat.push_back(e.second); }
+        uint64_t k = 0;
+        check(fcm_sampler_edgeset_neighborhood(s_.raw(), flat.data(), (uint32_t)edges.size(), nullptr, 0, &k));
+        std::vector<Node> out(k);
+        check(fcm_sampler_edgeset_neighborhood(s_.raw(), flat.data(), (uint32_t)edges.size(), out.data(), k, &k));
+        return out;
+    }
+    /// State::apply_transition (src/lib.rs:61-79)
+    Counters apply_transition(const Transition &t)
+    {
+        std::vector<fcm_node> e; std::vector<int32_t> a;
+        t.flat(e, a);
+        uint64_t pre[FCM_MAX_COUNTS], post[FCM_MAX_COUNTS];
+        int32_t pl = 0, ql = 0;
+        check(fcm_sampler_apply_transition(s_.raw(), chain_, e.data(), a.data(), (uint32_t)a.size(), pre, &pl, post, &ql));
+        return {std::vector<size_t>(pre, pre + pl), std::vector<size_t>(post, post + ql)};
+    }
+    /// State::revert_transition (src/lib.rs:81-95)
+    void revert_transition(const Transition &t, const Counters &c)
+    {
+        std::vector<fcm_node> e; std::vector<int32_t> a;
+        t.flat(e, a);
+        std::vector<uint64_t> pre(c.first.begin(), c.first.end()), post(c.second.begin(), c.second.end());
+        check(fcm_sampler_revert_transition(s_.raw(), chain_, e.data(), a.data(), (uint32_t)a.size(), pre.data(), (int32_t)pre.size(),
+                                            post.data(), (int32_t)post.size()));
+    }
+    /// Transition::single_edge_flip (src/lib.rs:292-299); x = one uniform 64-bit number from the caller's rng
+    Transition single_edge_flip(uint64_t x)
+    {
+        fcm_node e[4]; int32_t a[2]; uint32_t n = 0;
+        check(fcm_sampler_single_edge_flip(s_.raw(), chain_, x, e, a, &n));
+        Transition t;
+        for (uint32_t i = 0; i < n; ++i) t.change_edges.push_back({{e[2 * i], e[2 * i + 1]}, a[i] != 0});
+        return t;
+    }
+
+private:
+    MCMCSampler &s_;
+    uint32_t chain_;
+};
+
+/// Chains sharded over several devices of one node: one handle per entry of `devices`, each driven by its own host
+/// thread (the reference's only multi-chain precedent runs its States on OS threads: src/bin/all_cxs.rs:33-38).
+/// Global chain c belongs to shard c / ceil(C/G) and draws from stream (seed, c), so every result equals the
+/// single-handle run's, chain for chain, whatever the device list is (a device may be named more than once).
+class MultiDeviceSampler {
+public:
+    MultiDeviceSampler(const Graph &g, const Bounds &bounds, uint32_t n_chains, uint64_t seed, const double (&move_weights)[4],
+                       size_t sample_distance, const std::vector<int> &devices, int dim_cap = 0)
+    {
+        const uint32_t G = (uint32_t)devices.size();
+        if (G == 0) throw Error(FCM_ERR_INVALID, "no devices");
+        const uint32_t per = (n_chains + G - 1) / G;
+        std::vector<std::pair<uint32_t, uint32_t>> ranges;
+        for (uint32_t r = 0; r < G; ++r) {
+            const uint32_t lo = std::min(r * per, n_chains), hi = std::min(lo + per, n_chains);
+            if (hi > lo) { ranges.push_back({lo, hi}); devices_.push_back(devices[r]); }
+        }
+        shards_.resize(ranges.size());
+        parallel([&](size_t r) {
+            shards_[r].reset(new MCMCSampler(g, bounds, ranges[r].second - ranges[r].first, seed, move_weights, sample_distance,
+                                             devices_[r], dim_cap, ranges[r].first));
+        });
+        for (auto &r : ranges) first_.push_back(r.first);
+        n_chains_ = n_chains;
+    }
+    /// resumed shards (load_state of each shard's file)
+    explicit MultiDeviceSampler(std::vector<std::unique_ptr<MCMCSampler>> shards, std::vector<int> devices) : shards_(std::move(shards)), devices_(std::move(devices))
+    {
+        uint32_t at = 0;
+        for (auto &s : shards_) { first_.push_back(at); at += s->n_chains(); }
+        n_chains_ = at;
+    }
+    uint32_t n_chains() const { return n_chains_; }
+    size_t n_shards() const { return shards_.size(); }
+    MCMCSampler &shard(size_t r) { return *shards_[r]; }
+    int device(size_t r) const { return devices_[r]; }
+    size_t sample_distance() const { return shards_[0]->sample_distance(); }
+    /// MCMCSampler::next on every shard at once
+    void next() { parallel([&](size_t r) { shards_[r]->next(); }); }
+    void step(uint64_t n) { parallel([&](size_t r) { shards_[r]->step(n); }); }
+    /// the host-side gather: per-chain vectors of all shards in global chain order
+    std::vector<std::vector<size_t>> flag_counts()
+    {
+        std::vector<std::vector<std::vector<size_t>>> part(shards_.size());
+        parallel([&](size_t r) { part[r] = shards_[r]->flag_counts(); });
+        std::vector<std::vector<size_t>> out;
+        for (auto &p : part) out.insert(out.end(), p.begin(), p.end());
+        return out;
+    }
+    std::vector<MCMCSampler::Metrics> metrics()
+    {
+        std::vector<std::vector<MCMCSampler::Metrics>> part(shards_.size());
+        parallel([&](size_t r) { part[r] = shards_[r]->metrics(); });
+        std::vector<MCMCSampler::Metrics> out;
+        for (auto &p : part) out.insert(out.end(), p.begin(), p.end());
+        return out;
+    }
+    /// (shard, local chain) of a global chain id
+    std::pair<size_t, uint32_t> locate(uint32_t chain) const
+    {
+        size_t r = 0;
+        while (r + 1 < first_.size() && first_[r + 1] <= chain) ++r;
+        return {r, chain - first_[r]};
+    }
+    std::vector<uint8_t> edgebits(uint32_t chain) { const auto l = locate(chain); return shards_[l.first]->edgebits(l.second); }
+    Graph graph(uint32_t chain) { const auto l = locate(chain); return shards_[l.first]->graph(l.second); }
+    /// one state file per shard: <fname> for a single shard (the single-device layout), <fname>.shard<r> otherwise
+    static std::string shard_file(const std::string &fname, size_t r, size_t n_shards) { return n_shards == 1 ? fname : fname + ".shard" + std::to_string(r); }
+    void save_state(const std::string &fname, size_t sample_number)
+    {
+        parallel([&](size_t r) { shards_[r]->save_state(shard_file(fname, r, shards_.size()), sample_number); });
+    }
+    static std::pair<size_t, MultiDeviceSampler> load_state(const std::string &fname, const std::vector<int> &devices)
+    {
+        std::vector<std::unique_ptr<MCMCSampler>> shards;
+        std::vector<int> devs;
+        size_t sample_number = 0;
+        for (size_t r = 0; r < devices.size(); ++r) {
+            const std::string f = shard_file(fname, r, devices.size());
+            if (r > 0) { FILE *t = fopen(f.c_str(), "rb"); if (!t) break; fclose(t); }   // fewer shards than devices: chains < devices
+            auto ls = MCMCSampler::load_state(f, devices[r]);
+            sample_number = ls.first;
+            shards.emplace_back(new MCMCSampler(std::move(ls.second)));
+            devs.push_back(devices[r]);
+        }
+        return {sample_number, MultiDeviceSampler(std::move(shards), std::move(devs))};
+    }
+
+private:
+    // fn(r) for every shard, each on its own thread; the first exception is rethrown here once all have been joined
+    template <class F> void parallel(F fn)
+    {
+        const size_t G = shards_.size();
+        std::vector<std::exception_ptr> err(G);
+        std::vector<std::thread> th;
+        auto run = [&](size_t r) { try { fn(r); } catch (...) { err[r] = std::current_exception(); } };
+        size_t started = 1;
+        try { for (; started < G; ++started) th.emplace_back(run, started); } catch (...) {}
+        run(0);
+        for (size_t r = started; r < G; ++r) run(r);
+        for (auto &t : th) t.join();
+        for (auto &e : err) if (e) std::rethrow_exception(e);
+    }
+    std::vector<std::unique_ptr<MCMCSampler>> shards_;
+    std::vector<int> devices_;
+    std::vector<uint32_t> first_;
+    uint32_t n_chains_ = 0;
 };
 
 namespace io {
@@ -227,7 +409,7 @@ public:
         chunk_size_ = std::max<size_t>(2000000000 / (nslots / 8), 1);
     }
     ~BitOutput() { if (f_) fclose(f_); }
-    void save(MCMCSampler &s, uint32_t chain)
+    template <class Sampler> void save(Sampler &s, uint32_t chain)
     {
         if (index_in_file_ == 0) {
             f_ = fopen((dir_ + "/" + std::to_string(index_in_dir_) + ".edgebits").c_str(), "wb");
@@ -245,6 +427,8 @@ private:
     FILE *f_ = nullptr;
 };
 }  // namespace io
+
+inline State MCMCSampler::state(uint32_t chain) { return State(*this, chain); }
 
 static const double MOVE_DISTRIBUTION_SIMPLE[4] = {0.5, 0.5, 0.0, 0.0};  // src/bin/sample.rs:16
 static const double MOVE_DISTRIBUTION[4] = {0.1, 0.1, 0.6, 0.2};         // src/bin/sample.rs:17

@@ -2,7 +2,9 @@
 // driving a batch of chains on one GPU through libfcm.so.
 //
 // Same options as the reference's clap Args (src/bin/sample.rs:21-78) where
-// they apply, plus --chains / --device / --dim-cap.  Differences, all forced
+// they apply, plus --chains / --device / --devices / --dim-cap.  --devices 0,1,..: the chains are sharded over
+// the listed devices, one handle and one host thread each (fcm::MultiDeviceSampler); output is laid out as with one
+// device, chain for chain.  Differences, all forced
 // by scope: samples are written as edgebits only (--save-bits is
 // implied; HDF5 is out of scope).
 #include <cinttypes>
@@ -11,6 +13,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "directed_scm.hpp"
 
@@ -22,6 +25,7 @@ struct Args {
     bool simple = false;
     uint32_t chains = 1;
     int device = 0, dim_cap = 0;
+    std::vector<int> devices;   // --devices a,b,..: empty = the one --device
 };
 
 static void usage()
@@ -34,7 +38,7 @@ static void usage()
             "  -c, --continue-from <state>     --samples-store-dir <dir> [./samples/]\n"
             "  --state-store-dir <dir> [./state/]   --state-save-interval <k> [100]\n"
             "  --simple   only single edge flips and double edge moves     --save-bits (implied)\n"
-            "  --chains <n> [1]   --device <d> [0]   --dim-cap <d> [0 = lossless]\n");
+            "  --chains <n> [1]   --device <d> [0]   --devices <d0,d1,..> (chains sharded over them)   --dim-cap <d> [0 = lossless]\n");
 }
 
 static bool parse(int argc, char **argv, Args &a)
@@ -56,6 +60,17 @@ static bool parse(int argc, char **argv, Args &a)
         else if (k == "--simple") a.simple = true;
         else if (k == "--chains") a.chains = (uint32_t)strtoul(val(), nullptr, 10);
         else if (k == "--device") a.device = atoi(val());
+        else if (k == "--devices") {
+            const std::string v = val();
+            a.devices.clear();
+            for (size_t i = 0; i < v.size();) {
+                size_t j = v.find(',', i);
+                if (j == std::string::npos) j = v.size();
+                if (j > i) a.devices.push_back(atoi(v.substr(i, j - i).c_str()));
+                i = j + 1;
+            }
+            if (a.devices.empty()) { fprintf(stderr, "--devices needs a list\n"); return false; }
+        }
         else if (k == "--dim-cap") a.dim_cap = atoi(val());
         else if (k == "-h" || k == "--help") { usage(); exit(0); }
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return false; }
@@ -71,21 +86,21 @@ static void print_counts(const char *what, const std::vector<size_t> &v)
 }
 
 // initialize_new_sampler, src/bin/sample.rs:80-105
-static fcm::MCMCSampler initialize_new_sampler(const Args &args)
+static fcm::MultiDeviceSampler initialize_new_sampler(const Args &args, const std::vector<int> &devices)
 {
     fcm::Graph g = fcm::io::read_flag_file(args.input);
     printf("initial flagser\n");
-    const std::vector<size_t> flag_count = g.flagser_count(args.device);           // State::new, src/lib.rs:51
+    const std::vector<size_t> flag_count = g.flagser_count(devices[0]);           // State::new, src/lib.rs:51
     const fcm::Bounds target = fcm::Bounds::target(flag_count, args.target_relaxation);
-    const fcm::Bounds bounds = fcm::Bounds::calculate(g, flag_count, target, args.device);
+    const fcm::Bounds bounds = fcm::Bounds::calculate(g, flag_count, target, devices[0]);
     print_counts("  s^--: ", bounds.flag_count_min);
     print_counts("   s^-: ", target.flag_count_min);
     print_counts("  s(G): ", flag_count);
     print_counts("   s^+: ", target.flag_count_max);
     print_counts("  s^++: ", bounds.flag_count_max);
     // src/bin/sample.rs:101: --simple selects [0.5,0.5,0,0], the default is [0.1,0.1,0.6,0.2]
-    fcm::MCMCSampler s(g, bounds, args.chains, args.seed, args.simple ? fcm::MOVE_DISTRIBUTION_SIMPLE : fcm::MOVE_DISTRIBUTION,
-                       args.sample_distance, args.device, args.dim_cap);
+    fcm::MultiDeviceSampler s(g, bounds, args.chains, args.seed, args.simple ? fcm::MOVE_DISTRIBUTION_SIMPLE : fcm::MOVE_DISTRIBUTION,
+                              args.sample_distance, devices, args.dim_cap);
     printf("The sampling distance was set to %zu.\n", s.sample_distance());
     return s;
 }
@@ -95,17 +110,23 @@ int main(int argc, char **argv)
     Args args;
     if (!parse(argc, argv, args)) { usage(); return 2; }
     if (args.continue_from.empty() && (args.input.empty() || args.label.empty())) { usage(); return 2; }
+    const std::vector<int> devices = args.devices.empty() ? std::vector<int>{args.device} : args.devices;
     try {
         mkdir(args.state_store_dir.c_str(), 0777);
         mkdir(args.samples_store_dir.c_str(), 0777);
         size_t sample_index_start = 0;
-        std::unique_ptr<fcm::MCMCSampler> sampler;
+        std::unique_ptr<fcm::MultiDeviceSampler> sampler;
         if (!args.continue_from.empty()) {                                       // src/bin/sample.rs:114-115
-            auto ls = fcm::MCMCSampler::load_state(args.continue_from, args.device);
+            auto ls = fcm::MultiDeviceSampler::load_state(args.continue_from, devices);
             sample_index_start = ls.first;
-            sampler.reset(new fcm::MCMCSampler(std::move(ls.second)));
+            sampler.reset(new fcm::MultiDeviceSampler(std::move(ls.second)));
         } else {
-            sampler.reset(new fcm::MCMCSampler(initialize_new_sampler(args)));
+            sampler.reset(new fcm::MultiDeviceSampler(initialize_new_sampler(args, devices)));
+        }
+        if (sampler->n_shards() > 1) {
+            printf("%u chains on %zu handles:", sampler->n_chains(), sampler->n_shards());
+            for (size_t r = 0; r < sampler->n_shards(); ++r) printf(" device %d: %u", sampler->device(r), sampler->shard(r).n_chains());
+            printf("\n");
         }
         char seedbuf[32];
         snprintf(seedbuf, sizeof seedbuf, "%03" PRIu64, args.seed);
@@ -125,8 +146,8 @@ int main(int argc, char **argv)
                 printf("saving state in step %zu\n", i);
                 sampler->save_state(state_file, i);
             }
-            sampler->next();
-            const auto counts = sampler->flag_counts();
+            sampler->next();                                                      // every shard at once, one host thread each
+            const auto counts = sampler->flag_counts();                           // gathered on the host, global chain order
             const auto met = sampler->metrics();
             for (uint32_t c = 0; c < sampler->n_chains(); ++c) outs[c]->save(*sampler, c);
             print_counts("flag count: ", counts[0]);

@@ -48,7 +48,7 @@ extern "C" {
 
 /* Largest local vertex set a move may have (|N(a) cap N(b)| + 2).  Up to 64 vertices: the fast evaluator (one mask word
  * per lane); up to 256: the wide one (masks in LDS); up to 1024: masks in a per-chain workspace in HBM, allocated only for
- * graphs that have such a pair (simple moves; with clique moves on the limit is 256).  The counter (flagser_count) takes the
+ * graphs that have such a pair (simple moves and clique moves alike).  The counter (flagser_count) takes the
  * same 1024 common out-neighbours of a directed edge (beyond 256 in a second pass, for at most 4096 such edges).  The
  * reference has no such limits; beyond them: FCM_ERR_UNSUPPORTED. */
 #define FCM_MAX_LOCAL 1024
@@ -216,6 +216,46 @@ int fcm_sampler_get_edgebits(fcm_sampler *s, uint32_t chain, uint8_t *out, uint6
 int fcm_sampler_get_double_slots(fcm_sampler *s, uint32_t chain, uint32_t *out, uint64_t cap, uint64_t *n);
 
 /* ------------------------------------------------------------------------ */
+/* The State API on one chain of the batch: what the reference's search tools  */
+/* call between proposals (src/bin/seo_search_counterexample.rs:51-89,         */
+/* seo_bt_flip_only_once.rs:37-39,65-69, all_cxs.rs:54-86).  A Transition      */
+/* (src/lib.rs:200-204) is `n` change edges: edges[i] = [from, to],            */
+/* add[i] != 0 = add the edge, 0 = remove it.  Every change edge must lie on   */
+/* an adjacent pair of pr(G) -- the reference indexes edge_neighborhood with   */
+/* it and panics otherwise (FCM_ERR_PANIC).  Host-orchestrated (a few small    */
+/* launches and copies per call); the calls sync the handle's stream first.    */
+/* ------------------------------------------------------------------------ */
+/* State::edgeset_neighborhood (src/lib.rs:99-111): the union of the edges'    */
+/* common neighbourhoods and endpoints, ascending, deduplicated.  Writes        */
+/* min(cap, *k) vertices.                                                       */
+int fcm_sampler_edgeset_neighborhood(fcm_sampler *s, const fcm_node *edges /* [n][2] */, uint32_t n,
+                                     fcm_node *out, uint64_t cap, uint64_t *k);
+/* State::apply_transition (src/lib.rs:61-79) on chain `chain`: returns the    */
+/* reference's (pre, post) = flagser_count of the induced subgraph on the      */
+/* edge set's neighbourhood before and after the changes (pre, post: room for  */
+/* FCM_MAX_COUNTS entries each; *_len = the vectors' lengths), and updates the */
+/* chain's graph and flag_count.  If the reference's `assert!(*s >= *p)`       */
+/* (:65) would fire: FCM_ERR_PANIC and nothing is changed.  Not supported      */
+/* (FCM_ERR_UNSUPPORTED, nothing changed): a transition that changes the       */
+/* NUMBER of reciprocal pairs (the kernels draw double-edge moves over a fixed */
+/* number of slots; none of the reference's own move generators does that), or */
+/* that leaves an adjacent pair with no edge (pr(G) would change).             */
+int fcm_sampler_apply_transition(fcm_sampler *s, uint32_t chain, const fcm_node *edges /* [n][2] */, const int32_t *add /* [n] */,
+                                 uint32_t n, uint64_t *pre, int32_t *pre_len, uint64_t *post, int32_t *post_len);
+/* State::revert_transition (src/lib.rs:81-95): set_edge(a, b, !add) for every */
+/* change, flag_count -= post, += pre.  No counting.                           */
+int fcm_sampler_revert_transition(fcm_sampler *s, uint32_t chain, const fcm_node *edges, const int32_t *add, uint32_t n,
+                                  const uint64_t *pre, int32_t pre_len, const uint64_t *post, int32_t post_len);
+/* Transition::single_edge_flip (src/lib.rs:292-299) drawn on the chain's      */
+/* current graph, not applied.  The reference draws with the caller's rng;     */
+/* here the caller passes one uniform 64-bit number `x` (the draw itself is    */
+/* r = mulhi64(x, U + D) names a directed edge).  *n = 0 (empty   */
+/* transition: the edge's reverse is present, or the graph has no edge) or 2:  */
+/* edges = {[from,to], [to,from]}, add = {0, 1}.                               */
+int fcm_sampler_single_edge_flip(fcm_sampler *s, uint32_t chain, uint64_t x, fcm_node *edges /* [2][2] */, int32_t *add /* [2] */,
+                                 uint32_t *n);
+
+/* ------------------------------------------------------------------------ */
 /* Checkpoint / resume: the role of io::save_state / io::load_state           */
 /* (src/io.rs:51-62; called at src/bin/sample.rs:114-115,129-132,146).  Own    */
 /* format (the reference's is bincode of serde-derived types that live in the */
@@ -253,6 +293,19 @@ typedef struct {
 int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out);
 /* The Bounds the sampler checks against (MCMCSampler::bounds, src/lib.rs:170). */
 int fcm_sampler_get_bounds(const fcm_sampler *s, fcm_bounds *out);
+
+/* ------------------------------------------------------------------------ */
+/* Environment variables the library reads (all optional):                     */
+/*   FCM_DEVICE=<d>            device of the legacy flagser_count_unweighted   */
+/*   FCM_MW=<1|2|4|8|16>       waves per chain of the step kernel (a tuning    */
+/*                             override: trajectories do not depend on it)     */
+/*   FCM_TEST_GUARD_LIMIT=<v>  TEST HOOK: lowers the bound at which a local    */
+/*                             count is taken to risk passing 2^31 (DESIGN.md  */
+/*                             4.5), so that the tests can drive the guarded   */
+/*                             paths on small graphs.  Read once, at            */
+/*                             fcm_sampler_create.  Results are unchanged       */
+/*                             (wide 64-bit path) or the run fails loudly.      */
+/* ------------------------------------------------------------------------ */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,154 @@
+"""BASELINE.json's single-GPU shares at their STATED sizes, on the graphs themselves:
+
+  configs[1]  C. elegans stand-in (tests/golden/bug_calc_relax_de.flag, n = 279), 1024 chains, lossless and dim cap 5
+  configs[4]  n = 30000, 1M directed edge draws, 256 chains per GPU (29 GB of row bitmaps)
+
+Each: oracle twins (tolerance 0) on the graph itself, the full share with the size-independent checks (counts == a
+from-scratch recount, pr(G) and count[0..1] fixed, inside the bounds), and the soak of every W against the one-wave
+kernel.  configs[2] and [3] have theirs in tests/test_gpu_parity.py."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from helpers import compare_chain, load_flag_fixture, setup_pair
+
+pytestmark = pytest.mark.gpu
+U64_MAX = 2 ** 64 - 1
+
+
+def _strip(v):
+    v = list(v)
+    while v and v[-1] == 0:   # flag_count never shrinks in length (src/lib.rs:72-74)
+        v.pop()
+    return v
+
+
+def _pick(stats, want, keys=("n_redo", "n_big", "n_dmove")):
+    order = np.lexsort(tuple(-stats[k].astype(np.int64) for k in reversed(keys)))
+    return [int(c) for c in order[:want]]
+
+
+# ------------------------------------------------------------------ configs[4]: n = 30000, 256 chains
+@pytest.fixture(scope="module")
+def cfg5(fcm):
+    n = 30000
+    e = fcm.graphs.random_edge_draws(n, 1000000, 0)
+    return n, e
+
+
+def test_config5_oracle_twins_on_the_graph_itself(fcm, oracle, cfg5):
+    """Two chains x 60000 proposals (half of them double-edge moves) against their oracle twins: counts, counters,
+    every edge, the slot list.  Rows of 3840 B, local sets of 2-5 vertices: the n-tagged multi-wave kernel at W = 16.
+    target_relaxation 0: with the default 0.01 this graph's bounds are never reached in 60000 proposals, and a twin run
+    without a single rejection would not test the accept rule."""
+    n, e = cfg5
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e, relaxation=0.0)
+    assert gg.flagser_count() == go.flagser_count()
+    s = fcm.MCMCSampler(gg, b_g, n_chains=2, seed=0, first_chain_id=100)
+    assert s.info["waves_per_chain"] == 16 and s.info["row_words"] == 480
+    tw = [oracle.Chain(go, b_o, seed=0, chain_id=100 + c) for c in range(2)]
+    for nstep in (1, 2999, 57000):
+        s.step(nstep)
+        for c in range(2):
+            tw[c].step(nstep)
+            compare_chain(s, c, tw[c], ctx=("config5", c, nstep))
+    st = s.stats()
+    assert (st["status"] == 0).all() and (st["n_dmove"] > 20000).all() and (st["n_flip"] > 20000).all()
+    assert (st["accepted"] < st["sampled"]).all(), "no rejection in 60000 proposals: the bounds were never tested"
+
+
+def test_config5_full_share_256_chains(fcm, cfg5):
+    """The stated per-GPU share: 256 chains (29 GB of bitmaps), 4096 proposals each; recount of three chains."""
+    n, e = cfg5
+    g = fcm.Graph.from_edges(n, e)
+    s = fcm.initialize_new_sampler(g, n_chains=256, seed=1)
+    assert s.info["bytes_per_chain"] * 256 > 28e9
+    s.step(4096)
+    st = s.stats()
+    assert (st["status"] == 0).all() and (st["sampled"] == 4096).all() and (st["accepted"] <= st["sampled"]).all()
+    assert (st["n_empty"] + st["n_flip"] + st["n_dmove"] == 4096).all() and (st["n_dmove"] > 1500).all()
+    counts = s.flag_counts()
+    assert (counts[:, 0] == n).all() and (counts[:, 1] == len(e)).all()
+    und0 = g.undirected_edges()
+    for c in (0, 131, 255):
+        cur = s.graph(c)
+        assert cur.flagser_count() == _strip(s.flag_count(c))
+        assert cur.nedges() == len(e) and (cur.undirected_edges() == und0).all()
+        assert s.bounds.check(s.flag_count(c))
+    assert len({tuple(r) for r in counts.tolist()}) > 200   # the chains diverged
+    # chain 131 of this handle is chain 131 of any other: a fresh 1-chain handle ends in the same state
+    one = fcm.initialize_new_sampler(g, n_chains=1, seed=1, first_chain_id=131)
+    one.step(4096)
+    assert one.flag_count(0) == s.flag_count(131) and (one.edgebits(0) == s.edgebits(131)).all()
+
+
+# ------------------------------------------------------------------ configs[1]: n = 279, 1024 chains
+@pytest.fixture(scope="module")
+def celegans():
+    return load_flag_fixture("bug_calc_relax_de.flag")
+
+
+def test_config2_full_share_1024_chains_lossless(fcm, oracle, celegans):
+    n, e = celegans
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, b_g, n_chains=1024, seed=0)
+    assert s.info["lossless"] == 1 and s.ncounts == 8 and s.info["waves_per_chain"] == 8
+    nprop = 6000
+    s.step(nprop)
+    st = s.stats()
+    assert (st["status"] == 0).all() and (st["sampled"] == nprop).all()
+    assert (st["n_dmove"] == 0).all()                       # no reciprocal pairs: every double-edge move is empty
+    assert (st["n_empty"] + st["n_flip"] == nprop).all() and (st["accepted"] < st["sampled"]).all()
+    und0 = gg.undirected_edges()
+    for c in (0, 500, 1023):
+        cur = s.graph(c)
+        assert cur.flagser_count() == _strip(s.flag_count(c)) and (cur.undirected_edges() == und0).all()
+        assert s.bounds.check(s.flag_count(c))
+    assert st["n_redo"].sum() > 0 and st["n_big"].sum() > 0
+    for c in _pick(st, 4, keys=("n_redo", "n_big")):
+        tw = oracle.Chain(go, b_o, seed=0, chain_id=c)
+        tw.step(nprop)
+        compare_chain(s, c, tw, ctx=("config2", c))
+
+
+def test_config2_full_share_1024_chains_dim_cap_5(fcm, oracle, celegans):
+    """The cap BASELINE names.  pr(G) has 8-cliques, so cap 5 is the explicit truncated mode: dimensions 6
+    and 7 are neither tracked nor bounds-checked.  The oracle twin gets exactly that accept set -- the same bounds with
+    dimensions 6, 7 left open -- and must agree on every tracked count, every edge and every counter."""
+    n, e = celegans
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, b_g, n_chains=1024, seed=0, dim_cap=5)
+    assert s.info["lossless"] == 0 and s.ncounts == 6 and s.info["waves_per_chain"] == 8
+    nprop = 6000
+    s.step(nprop)
+    st = s.stats()
+    assert (st["status"] == 0).all() and (st["sampled"] == nprop).all()
+    for c in (0, 500, 1023):
+        assert s.graph(c).flagser_count()[:6] == s.flag_count(c)[:6]
+    mn, mx = b_o.lists()
+    open_b = oracle.Bounds.from_lists(mn[:6] + [0] * (len(mn) - 6), mx[:6] + [U64_MAX] * (len(mx) - 6))
+    differs = 0
+    for c in _pick(st, 4, keys=("n_redo", "n_big")):
+        tw = oracle.Chain(go, open_b, seed=0, chain_id=c)
+        tw.step(nprop)
+        ost = tw.stats()
+        for k in ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k"):
+            assert int(st[k][c]) == ost[k], (c, k)
+        assert s.flag_count(c)[:6] == tw.state.flag_count[:6]
+        assert (s.edges(c) == tw.state.graph_edges()).all()
+        full = oracle.Chain(go, b_o, seed=0, chain_id=c)
+        full.step(nprop)
+        differs += full.stats()["accepted"] != ost["accepted"]
+    # (whether the cap changed a trajectory at all is a property of the run; it is reported, not required)
+    print("dim cap 5: %d of 4 twin chains accept differently from the lossless run" % differs)
+
+
+# ------------------------------------------------------------------ every W against the one-wave kernel
+@pytest.mark.parametrize("cfg,chains,props", [(1, 64, 1 << 14), (4, 12, 1 << 14)])
+def test_multi_wave_soak_configs_1_and_4(fcm, cfg, chains, props):
+    spec = importlib.util.spec_from_file_location("mw_soak", os.path.join(os.path.dirname(__file__), "..", "tools", "mw_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.soak(cfg, chains, props, say=lambda m: None)

@@ -1,0 +1,164 @@
+"""The State API through the C ABI (fcm_sampler_apply_transition / _revert_transition / _single_edge_flip /
+_edgeset_neighborhood) against the oracle's restatement of State::apply_transition / revert_transition
+(reference src/lib.rs:61-111, 292-299; callers: src/bin/seo_search_counterexample.rs:51-89,
+seo_bt_flip_only_once.rs:65-69).  (pre, post) are compared as the reference returns them -- the counts of the
+induced subgraph before and after, lengths included -- not only their difference."""
+import numpy as np
+import pytest
+
+from helpers import setup_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _sampler(fcm, oracle, n, e, weights=(0.5, 0.5, 0.0, 0.0), n_chains=2):
+    gg, go, bg, bo = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, bg, n_chains=n_chains, seed=5, move_weights=weights)
+    return s, oracle.State(go), go, bo
+
+
+def _same(st_g, st_o, ctx=""):
+    assert st_g.flag_count == st_o.flag_count, ctx
+    ge, oe = st_g._s.edges(st_g._chain), st_o.graph_edges()
+    assert ge.shape == oe.shape and (ge == oe).all(), ctx
+
+
+def _reciprocal_ids(ue, edges):
+    have = {(int(a), int(b)) for a, b in edges}
+    return [i for i, (a, b) in enumerate(ue) if (int(a), int(b)) in have and (int(b), int(a)) in have]
+
+
+def test_apply_revert_ex04_to_ex05(fcm, oracle):
+    # ex04 -> ex05 is the flip of 3->1; both have counts [4, 5, 2]
+    e = fcm.graphs.densifier([0, 0, 1, 3, 3], [1, 2, 2, 1, 2])
+    s, so, _, _ = _sampler(fcm, oracle, 4, e)
+    sg = s.state(1)
+    t = fcm.Transition([((3, 1), False), ((1, 3), True)])
+    assert sg.edgeset_neighborhood([(3, 1)]) == so.edgeset_neighborhood([(3, 1)])
+    pre, post = sg.apply_transition(t)
+    assert (pre, post) == so.apply_transition(t.change_edges)
+    _same(sg, so)
+    assert sg.flag_count == [4, 5, 2]
+    assert sorted(map(tuple, s.edges(1).tolist())) == sorted(map(tuple, fcm.graphs.densifier([0, 0, 1, 1, 3], [1, 2, 2, 3, 2]).tolist()))
+    assert s.flag_count(0) == [4, 5, 2] and (s.edges(0) == np.array(sorted(map(tuple, e.tolist())), np.uint32)).all()   # the other chain is untouched
+    sg.revert_transition(t, (pre, post))
+    so.revert_transition(t.change_edges, (pre, post))
+    _same(sg, so)
+    # the empty transition (src/lib.rs:298): empty neighbourhood, nothing changes
+    pe, qe = sg.apply_transition(fcm.Transition([]))
+    assert (pe, qe) == so.apply_transition([])
+    _same(sg, so)
+
+
+def test_random_transitions_against_the_oracle(fcm, oracle):
+    n = 70
+    e = fcm.graphs.random_with_p(n, 0.22, seed=11)
+    s, so, go, _ = _sampler(fcm, oracle, n, e, weights=(0.1, 0.1, 0.6, 0.2))     # clique-move sampler: slot_of is kept too
+    sg = s.state(0)
+    ue = so.undirected_edges()
+    rng = np.random.default_rng(3)
+    history = []
+    nontrivial = 0
+    for it in range(200):
+        cur = {(int(a), int(b)) for a, b in so.graph_edges()}
+        single = [(int(a), int(b)) for a, b in ue if ((int(a), int(b)) in cur) != ((int(b), int(a)) in cur)]
+        recip = [(int(a), int(b)) for a, b in ue if (int(a), int(b)) in cur and (int(b), int(a)) in cur]
+        kind = it % 4
+        ch = []
+        if kind == 0:      # a flip, written as the reference's generators do
+            a, b = single[rng.integers(len(single))]
+            f, t_ = (a, b) if (a, b) in cur else (b, a)
+            ch = [((f, t_), False), ((t_, f), True)]
+        elif kind == 1:    # the shape of double_edge_move: one direction of a reciprocal pair goes, a single edge gets its reverse
+            a, b = recip[rng.integers(len(recip))]
+            c, d = single[rng.integers(len(single))]
+            f, t_ = (c, d) if (c, d) in cur else (d, c)
+            ch = [((t_, f), True), (((a, b) if rng.integers(2) else (b, a)), False)]
+        elif kind == 2:    # several flips at once (a union neighbourhood, like a clique move's)
+            for j in rng.choice(len(single), size=4, replace=False):
+                a, b = single[j]
+                f, t_ = (a, b) if (a, b) in cur else (b, a)
+                ch += [((f, t_), False), ((t_, f), True)]
+        else:              # undo something
+            if history:
+                tt, cnt = history.pop()
+                sg.revert_transition(fcm.Transition(tt), cnt)
+                so.revert_transition(tt, cnt)
+                _same(sg, so, "revert %d" % it)
+            continue
+        assert sg.edgeset_neighborhood([c[0] for c in ch]) == so.edgeset_neighborhood([c[0] for c in ch])
+        got = sg.apply_transition(fcm.Transition(ch))
+        want = so.apply_transition(ch)
+        assert got == want, (it, ch, got, want)
+        nontrivial += got[0] != got[1]
+        _same(sg, so, "apply %d" % it)
+        history = [(ch, got)]     # only the latest transition can be reverted exactly (the reference keeps no stack either)
+    assert nontrivial > 50
+    # the sampler goes on from the state the API left: slot list = the reciprocal pairs, counts = a full recount
+    assert sorted(int(x) for x in s.double_slots(0)) == _reciprocal_ids(ue, s.edges(0))
+    s.step(400)
+    assert (s.stats()["status"] == 0).all()
+    for c in (0, 1):
+        assert s.graph(c).flagser_count() == s.flag_count(c)[: len(s.graph(c).flagser_count())]
+        assert sorted(int(x) for x in s.double_slots(c)) == _reciprocal_ids(ue, s.edges(c))
+
+
+def test_greedy_search_loop_like_the_reference_tool(fcm, oracle):
+    """The loop of src/bin/seo_search_counterexample.rs:51-89 on both sides: draw a flip, apply, keep it only if the
+    number of 2-simplices grew, else revert."""
+    n = 60
+    e = fcm.graphs.seoify(fcm.graphs.random_with_p(n, 0.3, seed=2), seed=2)
+    s, so, go, _ = _sampler(fcm, oracle, n, e, n_chains=1)
+    sg = s.state(0)
+    ue = so.undirected_edges()
+    U = len(ue)
+    rng = np.random.default_rng(9)
+    kept = 0
+    for it in range(300):
+        x = int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2))
+        t = fcm.Transition.single_edge_flip(sg, x)
+        # the same draw on the oracle's graph (no reciprocal pairs here, so D = 0)
+        r = (x * U) >> 64
+        big, small = int(ue[r][0]), int(ue[r][1])
+        g_o = so.graph()
+        f, t_ = (big, small) if g_o.has_edge(big, small) else (small, big)
+        assert t.change_edges == [((f, t_), False), ((t_, f), True)], it
+        pre, post = sg.apply_transition(t)
+        assert (pre, post) == so.apply_transition(t.change_edges), it
+        accept = not (len(post) < len(pre)) and not (len(post) > 2 and len(pre) > 2 and post[2] <= pre[2])
+        if not accept:
+            sg.revert_transition(t, (pre, post))
+            so.revert_transition(t.change_edges, (pre, post))
+        kept += accept
+        assert sg.flag_count == so.flag_count, it
+    assert 10 < kept < 290
+    _same(sg, so)
+    assert sg.flag_count[2] > go.flagser_count()[2]
+
+
+def test_transitions_the_api_refuses_change_nothing(fcm, oracle):
+    n = 40
+    e = fcm.graphs.random_with_p(n, 0.25, seed=4)
+    s, so, go, _ = _sampler(fcm, oracle, n, e)
+    sg = s.state(0)
+    before = (sg.flag_count, s.edges(0).tolist(), s.double_slots(0).tolist())
+    und = {(int(a), int(b)) for a, b in so.undirected_edges()}
+    cur = {(int(a), int(b)) for a, b in e}
+    non_adjacent = next((a, b) for a in range(n) for b in range(a) if (a, b) not in und)
+    with pytest.raises(fcm.FcmError) as ei:       # the reference panics on the HashMap index (src/lib.rs:104)
+        sg.apply_transition(fcm.Transition([(non_adjacent, True)]))
+    assert ei.value.code == fcm._ffi.ERR_PANIC
+    a, b = next((a, b) for a, b in und if ((a, b) in cur) != ((b, a) in cur))
+    f, t_ = (a, b) if (a, b) in cur else (b, a)
+    with pytest.raises(fcm.FcmError) as ei:       # one more reciprocal pair
+        sg.apply_transition(fcm.Transition([((t_, f), True)]))
+    assert ei.value.code == fcm._ffi.ERR_UNSUPPORTED
+    with pytest.raises(fcm.FcmError) as ei:       # the pair's only edge goes
+        sg.apply_transition(fcm.Transition([((f, t_), False)]))
+    assert ei.value.code == fcm._ffi.ERR_UNSUPPORTED
+    with pytest.raises(fcm.FcmError):
+        sg.apply_transition(fcm.Transition([((n, 0), True)]))
+    with pytest.raises(fcm.FcmError) as ei:       # counts that are not there: the reference's assert!(*s >= *p)
+        sg.revert_transition(fcm.Transition([((f, t_), False), ((t_, f), True)]), ([n, 10 ** 9], [n, 10 ** 9, 10 ** 9]))
+    assert ei.value.code == fcm._ffi.ERR_PANIC
+    assert before == (sg.flag_count, s.edges(0).tolist(), s.double_slots(0).tolist())
