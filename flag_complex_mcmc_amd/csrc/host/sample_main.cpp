@@ -78,6 +78,13 @@ static bool parse(int argc, char **argv, Args &a)
     return true;
 }
 
+// std::fs::create_dir_all (src/bin/sample.rs:109-110): every missing component, existing ones are fine
+static void create_dir_all(const std::string &path)
+{
+    for (size_t i = 1; i <= path.size(); ++i)
+        if (i == path.size() || path[i] == '/') mkdir(path.substr(0, i).c_str(), 0777);
+}
+
 static void print_counts(const char *what, const std::vector<size_t> &v)
 {
     printf("%s[", what);
@@ -112,8 +119,8 @@ int main(int argc, char **argv)
     if (args.continue_from.empty() && (args.input.empty() || args.label.empty())) { usage(); return 2; }
     const std::vector<int> devices = args.devices.empty() ? std::vector<int>{args.device} : args.devices;
     try {
-        mkdir(args.state_store_dir.c_str(), 0777);
-        mkdir(args.samples_store_dir.c_str(), 0777);
+        create_dir_all(args.state_store_dir);
+        create_dir_all(args.samples_store_dir);
         size_t sample_index_start = 0;
         std::unique_ptr<fcm::MultiDeviceSampler> sampler;
         if (!args.continue_from.empty()) {                                       // src/bin/sample.rs:114-115

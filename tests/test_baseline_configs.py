@@ -77,7 +77,7 @@ def test_config5_full_share_256_chains(fcm, cfg5):
         assert cur.flagser_count() == _strip(s.flag_count(c))
         assert cur.nedges() == len(e) and (cur.undirected_edges() == und0).all()
         assert s.bounds.check(s.flag_count(c))
-    assert len({tuple(r) for r in counts.tolist()}) > 200   # the chains diverged
+    assert len({tuple(r) for r in counts.tolist()}) > 30 and not (s.edgebits(0) == s.edgebits(255)).all()   # the chains diverged (only count[2] moves on this graph)
     # chain 131 of this handle is chain 131 of any other: a fresh 1-chain handle ends in the same state
     one = fcm.initialize_new_sampler(g, n_chains=1, seed=1, first_chain_id=131)
     one.step(4096)

@@ -335,6 +335,24 @@ def test_count_wide_common_out_neighbourhood(fcm, oracle, t):
 
 
 # -------------------------------------------------- edgebits (src/io.rs) -----
+def test_count_second_pass_refuses_dimensions_it_does_not_track(fcm, oracle):
+    """A directed 17-clique (a simplex of dimension 16) whose first edge has 300 common out-neighbours: only the
+    counter's second pass (fcm_count_xw_kernel, 257..1024 common out-neighbours) walks it, and it must refuse like the
+    first pass does -- count vectors hold dimensions 0..15 -- instead of returning truncated counts.  One vertex fewer
+    (dimension 15) is counted, and equals the oracle."""
+    def graph(t):
+        w = list(range(2, 302))
+        e = [(0, 1)] + [(0, x) for x in w] + [(1, x) for x in w] + [(w[i], w[j]) for i in range(t) for j in range(i + 1, t)]
+        return 302, np.array(e, np.uint32)
+    n, e = graph(14)
+    fc = fcm.Graph.from_edges(n, e).flagser_count()
+    assert len(fc) == 16 and fc[15] == 1 and fc == oracle.Graph.from_edges(n, e).flagser_count()
+    n, e = graph(15)
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.Graph.from_edges(n, e).flagser_count()
+    assert ei.value.code == fcm._ffi.ERR_UNSUPPORTED and "dimension" in str(ei.value)
+
+
 def test_edgebits_layout(fcm, tmp_path):
     from flag_complex_mcmc_amd import graphs
     e = graphs.random_with_p(40, 0.3, seed=1)
