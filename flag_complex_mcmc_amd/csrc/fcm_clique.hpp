@@ -92,6 +92,8 @@ struct CliqueResult {
     long long wide_d; // this lane's share of deltas that came through the wide path
     u32 status;
     u32 n_wide;       // pairs of this move that took a multi-word evaluator
+    int n_d;          // vertices involved (entries of CL.d)
+    u32 oldt, newt;   // per lane t < n_d: in-masks over d before / after the move (bit u = d[u] -> d[t]), among the touched pairs
 };
 
 // One direction of a changed pair on the wide evaluator (its counts are 64-bit): the edge is in the bitmap while it is
@@ -115,24 +117,40 @@ __device__ __forceinline__ void clique_dir_wide(u64 *smem, int maxnw, u32 *rows,
     res.n_wide += 1u;
 }
 
-// Builds the changed-pair list of a clique move and applies it to the bitmap,
-// adding the simplex-count change to `delta` (fast evaluations) and res.wide_d
-// (wide).  move == 2: clique_permute, 3: clique_swap.
-template <int MAXT, bool XW>
-__device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, const rsrc_t rrows, u64 *smem, const CliqueLds CL, int move,
-                                                       u32 w1, u64 x64, u64 step, u32 gchain, u32 k0, u32 k1, int lane, int tmax,
-                                                       int maxnw, int (&delta)[MAXT + 1], EvScal &es, u64 *sacc, u64 *stt, FcmGuard *guard = nullptr)
+// What the setup of a clique move needs of the launch parameters (the cooperative kernel hands them over from LDS).
+struct CliqueTables {
+    const u32 *clq, *clq_pairs;
+    const FcmEdgeEntry *etab;
+    const uint64_t *cl_base, *cl_count, *clp_base, *cumo;   // [FCM_DEV_MAX_COUNTS] each
+    int cl_orders;
+    u32 chg_cap, stride32;
+};
+__device__ __forceinline__ CliqueTables clique_tables(const FcmStepParams &p)
 {
-    CliqueResult res = {0, 0, 0ull, 0ll, 0u, 0u};
-    u64 *Hp = smem + WAVE;
+    return CliqueTables{p.clq, p.clq_pairs, p.etab, p.cl_base, p.cl_count, p.clp_base, p.cumo, p.cl_orders, p.chg_cap, p.stride32};
+}
+
+// The proposal itself (src/lib.rs:214-290): picks the clique(s), draws the permutation(s), gathers OLD, forms NEW and
+// lists the vertex pairs whose orientation changes in CL.chg (4 words per pair: d indices and old / new 2-bit states,
+// etab index, k, nb_off), ascending (i, j).  Nothing is written to the bitmap.  move == 2: clique_permute, 3: clique_swap.
+__device__ __forceinline__ CliqueResult clique_setup(const CliqueTables &p, const u32 *rows, const CliqueLds CL, int move, u32 w1, u64 x64, u64 step,
+                                                     u32 gchain, u32 k0, u32 k1, int lane, u64 *sacc, u64 *stt)
+{
+    CliqueResult res = {0, 0, 0ull, 0ll, 0u, 0u, 0, 0u, 0u};
     const u32 stride32 = p.stride32;
     // ---- clique_order_distribution.sample, cliques.choose (src/lib.rs:215-216, 235-237)
+    // (the tables may sit in LDS -- the cooperative kernel -- where the compiler takes loaded values for per-lane ones:
+    //  everything read from them is pinned wave-uniform, or the loops below would run under exec masks)
+    auto uni32 = [](u32 v) -> u32 { return (u32)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uni64 = [&](u64 v) -> u64 { return (u64)uni32((u32)v) | ((u64)uni32((u32)(v >> 32)) << 32); };
+    const int n_orders = (int)uni32((u32)p.cl_orders);
     int oi = 0;
-    while (oi < p.cl_orders - 1 && (u64)w1 >= p.cumo[oi]) ++oi;
+    while (oi < n_orders - 1 && (u64)w1 >= uni64(p.cumo[oi])) ++oi;
+    oi = (int)uni32((u32)oi);
     const int o = oi + 1;
-    const u64 cnt = p.cl_count[oi];
+    const u64 cnt = uni64(p.cl_count[oi]);
     if (cnt == 0) { res.status = 16u; return res; }
-    const u32 *bucket = p.clq + p.cl_base[oi];
+    const u32 *bucket = p.clq + uni64(p.cl_base[oi]);
     const u32 NONE = 0xFFFFFFFFu;
     const u64 c1 = __umul64hi(x64, cnt);
     u64 c2 = c1;
@@ -232,6 +250,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
         oldt |= ((CL.oldm[j] >> lane) & 1u) << j;
         newt |= ((CL.newm[j] >> lane) & 1u) << j;
     }
+    res.n_d = n_d; res.oldt = oldt; res.newt = newt;
     const u32 upper = act ? ~((2u << lane) - 1u) : 0u;  // each pair once: j > lane
     const u32 chm = ((oldr ^ newr) | (oldt ^ newt)) & upper;
     const int mine = __popc(chm);
@@ -256,7 +275,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
     CLQ_STAMP(2);                                                      // OLD gather, NEW, pair list
     // ---- table entries of all changed pairs, in parallel
     {
-        const u32 *ptab = p.clq_pairs + p.clp_base[oi];
+        const u32 *ptab = p.clq_pairs + uni64(p.clp_base[oi]);
         const u32 npo = (u32)(o * (o - 1) / 2);
         bool bad = false;
         for (int x = lane; x < npairs; x += WAVE) {
@@ -280,6 +299,25 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
     }
     wave_sync();
     CLQ_STAMP(3);                                                      // pair ids + table entries
+    return res;
+}
+
+// Builds the changed-pair list of a clique move and applies it to the bitmap,
+// adding the simplex-count change to `delta` (fast evaluations) and res.wide_d
+// (wide).  move == 2: clique_permute, 3: clique_swap.  (The one-wave kernel: a pair's change is stored before the next
+// pair's rows are read, and a rejected move is put back; the cooperative kernel, fcm_step_cq.hpp, evaluates every pair
+// on the pre-move bitmap instead.)
+template <int MAXT, bool XW>
+__device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, const rsrc_t rrows, u64 *smem, const CliqueLds CL, int move,
+                                                       u32 w1, u64 x64, u64 step, u32 gchain, u32 k0, u32 k1, int lane, int tmax,
+                                                       int maxnw, int (&delta)[MAXT + 1], EvScal &es, u64 *sacc, u64 *stt, FcmGuard *guard = nullptr)
+{
+    const CliqueTables T = clique_tables(p);
+    CliqueResult res = clique_setup(T, rows, CL, move, w1, x64, step, gchain, k0, k1, lane, sacc, stt);
+    if (res.nchg == 0) return res;
+    const int npairs = res.npairs;
+    u64 *Hp = smem + WAVE;
+    const u32 stride32 = p.stride32;
     // ---- apply one pair at a time, counting each directed change
     for (int x = 0; x < npairs; ++x) {
         const u32 w0 = CL.chg[4 * x], off = CL.chg[4 * x + 3];

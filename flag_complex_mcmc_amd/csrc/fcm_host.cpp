@@ -695,6 +695,7 @@ struct fcm_sampler {
     // device buffers
     DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats, d_clq, d_clq_pairs, d_efirst, d_slot_of, d_dbg, d_xw;
     bool clique_moves = false;
+    bool use_cq = false;               // move mixes with clique moves on the fcm_step_cq kernel (<= 8 count entries)
     // host copies of the static tables, fetched on the first use of the State API (apply/revert/edgeset_neighborhood)
     std::vector<FcmEdgeEntry> h_etab;
     std::vector<uint32_t> h_nb;
@@ -999,7 +1000,7 @@ try {
         p.slot_of = s->d_slot_of.as<uint32_t>();
         for (int o = 0; o < FCM_MAX_COUNTS; ++o) { p.cl_base[o] = ct.base[o]; p.cl_count[o] = ct.count[o]; p.cumo[o] = cumo[o]; }
         p.cl_orders = ct.orders;
-        p.chg_cap = (uint32_t)std::max(32, 4 * ct.orders * ct.orders);   // u64 words: 4 u32 per vertex pair of two cliques
+        p.chg_cap = (uint32_t)std::max(32, 2 * ct.orders * ct.orders);   // u64 words: 4 u32 per vertex pair, at most o(o-1) changed pairs (two cliques of a swap)
     }
     p.seed = cfg->seed;
     p.rows_per_chain = rows_per_chain;
@@ -1050,6 +1051,10 @@ try {
         if (s->clique_moves || nc - 2 < 2 || nc - 2 > 6) W = 1u;
         I.waves_per_chain = W;
         p.mw_waves = W >= 2 ? W : 0u;
+        // Move mixes with clique moves: the kernel that evaluates a move's pairs on the pre-move bitmap (fcm_step_cq.hpp), for
+        // up to 8 count entries like the multi-wave kernel; otherwise, or with FCM_CQ=0, the one-wave kernel's clique path.
+        const char *cq = getenv("FCM_CQ");
+        s->use_cq = s->clique_moves && nc - 2 >= 2 && nc - 2 <= 6 && !(cq && atoi(cq) == 0);
     }
 
     guard.s = nullptr;
@@ -1081,7 +1086,7 @@ try {
     while (left > 0) {
         const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
         s->params.nprop = chunk;
-        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? 1 : (s->info.waves_per_chain >= 2 ? 2 : 0), s->stream);
+        int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? (s->use_cq ? 3 : 1) : (s->info.waves_per_chain >= 2 ? 2 : 0), s->stream);
         if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
         left -= chunk;
     }

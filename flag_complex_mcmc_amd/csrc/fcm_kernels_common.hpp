@@ -72,6 +72,8 @@ __device__ __forceinline__ u32 wrlane(u32 src, int l, u32 old)
     return (u32)__builtin_amdgcn_writelane((int)src, l, (int)old);
 #else
     // two SGPR sources would break the constant-bus limit: the lane select goes through m0
+    // (the value is made opaque first: a constant folded into the "s" operand may come out as a literal the instruction does not take)
+    asm volatile("" : "+s"(src));
     asm volatile("s_nop 0\n\ts_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(src), "s"(l) : "m0");
     return old;
 #endif

@@ -708,7 +708,7 @@ __device__ __attribute__((noinline)) void mw_fill_table(u64 *smem, u32 wv, u32 q
     }
     if (lane < (int)MW_TBL_N) {
         u32 *t = T + j * MW_TBL_WORDS;
-        t[0] = (u32)mv | ((w[1] & 1u) << 8); t[1] = ed; t[2] = (u32)ix; t[3] = (u32)(ix >> 32);
+        t[0] = (u32)mv | ((w[1] & 1u) << 8); t[1] = mv >= 2 ? w[1] : ed; t[2] = (u32)ix; t[3] = (u32)(ix >> 32);   // (clique moves, fcm_step_cq.hpp: the whole of w1 picks the order)
         t[4] = e.big; t[5] = e.small; t[6] = e.nb_off; t[7] = e.k;
         t[8] = de.big; t[9] = de.small; t[10] = de.nb_off; t[11] = de.k;
         t[12] = c0; t[13] = c1;

@@ -5,6 +5,7 @@
 //   EXACT=0: tmax <= FCM_MAXT at run time (tags 6_0, 14_0, 6_1, 14_1).
 #include "fcm_kernels_common.hpp"
 #include "fcm_step_mw.hpp"
+#include "fcm_step_cq.hpp"
 
 #if !defined(FCM_MAXT) || !defined(FCM_CLIQUE) || !defined(FCM_EXACT) || !defined(FCM_TAG)
 #error "compile with -DFCM_TAG=.. -DFCM_MAXT=.. -DFCM_EXACT=0|1 -DFCM_CLIQUE=0|1"
@@ -20,7 +21,16 @@
 #define FCM_MINW 1
 #endif
 
-#if defined(FCM_PC) && FCM_PC
+#if defined(FCM_PC) && FCM_PC >= 3
+// tags c2_1 .. c6_1 (rows of one cache line, FCM_PC=3) and d2_1 .. d6_1 (longer rows, FCM_PC=4): the step kernel for move
+// mixes with clique moves (fcm_step_cq.hpp): pairs of a move on the pre-move bitmap, one commit on accept
+extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
+{
+    const size_t words = fcm_cq_lds_words(p->maxnw < 2 ? 2 : p->maxnw, p->chg_cap);
+    fcm_step_cq_kernel<FCM_MAXT, FCM_PC == 3, true><<<dim3(p->nchains), dim3(WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
+    return (int)hipGetLastError();
+}
+#elif defined(FCM_PC) && FCM_PC
 // tags m2_0 .. m6_0 (rows of one cache line, FCM_PC=1) and n2_0 .. n6_0 (longer rows, FCM_PC=2): the
 // multi-wave kernel (p->mw_waves waves per chain, in-order commit), simple moves only
 extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
