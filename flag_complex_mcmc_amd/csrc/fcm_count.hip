@@ -217,9 +217,6 @@ int fcm_launch_step_n6_0(const FcmStepParams *, void *);
 int fcm_launch_step_c2_1(const FcmStepParams *, void *); int fcm_launch_step_c3_1(const FcmStepParams *, void *);
 int fcm_launch_step_c4_1(const FcmStepParams *, void *); int fcm_launch_step_c5_1(const FcmStepParams *, void *);
 int fcm_launch_step_c6_1(const FcmStepParams *, void *);
-int fcm_launch_step_d2_1(const FcmStepParams *, void *); int fcm_launch_step_d3_1(const FcmStepParams *, void *);
-int fcm_launch_step_d4_1(const FcmStepParams *, void *); int fcm_launch_step_d5_1(const FcmStepParams *, void *);
-int fcm_launch_step_d6_1(const FcmStepParams *, void *);
 }
 
 // tmax = tracked depth (count entries - 2); clique: kernel variant with the clique moves
@@ -237,10 +234,9 @@ extern "C" int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, voi
                                                 fcm_launch_step_n5_0, fcm_launch_step_n6_0};   // longer rows
         return (p->stride32 == 32u ? mc : nc)[tmax - 2](p, stream);
     }
-    if (clique == 3 && tmax >= 2 && tmax <= 6) {   // move mixes with clique moves: pairs on the pre-move bitmap (fcm_step_cq.hpp)
+    if (clique == 3 && tmax >= 2 && tmax <= 6) {   // move mixes with clique moves: pairs on the pre-move bitmap, W waves per chain (fcm_step_cq.hpp)
         static const fcm_step_launcher cc[5] = {fcm_launch_step_c2_1, fcm_launch_step_c3_1, fcm_launch_step_c4_1, fcm_launch_step_c5_1, fcm_launch_step_c6_1};
-        static const fcm_step_launcher dc[5] = {fcm_launch_step_d2_1, fcm_launch_step_d3_1, fcm_launch_step_d4_1, fcm_launch_step_d5_1, fcm_launch_step_d6_1};
-        return (p->stride32 == 32u ? cc : dc)[tmax - 2](p, stream);
+        return cc[tmax - 2](p, stream);
     }
     if (c && p->xw_ws) return tmax <= 6 ? fcm_launch_step_6_2(p, stream) : fcm_launch_step_14_2(p, stream);   // clique moves on a graph with a local set beyond 256 vertices
     if (tmax >= 2 && tmax <= 6) return exact[tmax - 2][c](p, stream);

@@ -1055,6 +1055,14 @@ try {
         // up to 8 count entries like the multi-wave kernel; otherwise, or with FCM_CQ=0, the one-wave kernel's clique path.
         const char *cq = getenv("FCM_CQ");
         s->use_cq = s->clique_moves && nc - 2 >= 2 && nc - 2 <= 6 && !(cq && atoi(cq) == 0);
+        if (s->use_cq) {
+            // W waves per chain share a move's pairs: as many as keep chains x W within the 4096 wave slots of 4 waves per SIMD
+            // (128 VGPRs), at most 8 (a move changes about 6 pairs).  FCM_CQW=<1|2|4|8> overrides.
+            uint32_t Wc = C > 2048 ? 1u : (C > 1024 ? 2u : (C > 512 ? 4u : 8u));
+            if (const char *e = getenv("FCM_CQW")) { const int v = atoi(e); Wc = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; }
+            I.waves_per_chain = Wc;
+            p.mw_waves = Wc >= 2 ? Wc : 0u;
+        }
     }
 
     guard.s = nullptr;

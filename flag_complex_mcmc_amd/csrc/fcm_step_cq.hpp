@@ -1,8 +1,9 @@
-// fcm_step_cq.hpp — the step kernel for move mixes WITH clique moves (reference default [0.1, 0.1, 0.6, 0.2],
-// src/bin/sample.rs:17,101; clique_permute / clique_swap, src/lib.rs:214-290).  Included by fcm_step_variant.hip for
-// the c<depth> (rows of one cache line) and d<depth> (longer rows) tags; 2 <= depth <= 6, like the multi-wave kernel.
+// fcm_step_cq.hpp — the cooperative step kernel for move mixes WITH clique moves (reference default [0.1, 0.1, 0.6, 0.2],
+// src/bin/sample.rs:17,101; clique_permute / clique_swap, src/lib.rs:214-290).  Included by fcm_step_variant.hip for the
+// c<depth> tags; 2 <= depth <= 6 (up to 8 count entries), like the multi-wave kernel of the simple moves.
 //
-// One 64-lane workgroup per chain.  What differs from the one-wave kernel's clique path (fcm_clique.hpp, clique_propose):
+// W waves per chain (W = 1, 2, 4, 8: a launch parameter), one proposal at a time.  What differs from the one-wave
+// kernel's clique path (fcm_clique.hpp, clique_propose):
 //
 //  * Every changed vertex pair of a move is evaluated on the PRE-MOVE bitmap.  The reference applies a move's change
 //    edges one by one and recounts in between (State::apply_transition, src/lib.rs:61-79); the telescoping sum needs
@@ -11,57 +12,74 @@
 //    masks in registers (cq_patch) instead of being stored to memory and read back.  Nothing is written until the move
 //    is accepted -- one pass of stores, all pairs at once -- and a rejected move needs no revert (the reference's
 //    revert_transition, :81-95, has nothing to undo).
-//  * The pairs' builds no longer depend on each other through memory, so they are software-pipelined: while pair x is
-//    evaluated, the rows of pair x+1 are in flight (a fixed 24 whole-row loads per pair, so that the wait counts are
-//    static) and the vertex list of pair x+2 is on its way.
-//  * Lean register allocation: the chain's context lives in LDS, the simple moves (20 % of the default mix) run
-//    out of line through the multi-wave kernel's exact run (mw_exact_call), so the pair loop is all the hot code
-//    there is.  (In the one-wave kernel a quarter of the VALU instructions were reloads of spilled scalars.)
+//  * That makes the pairs of a move independent of each other: wave w of the chain's workgroup takes the pairs
+//    w, w+W, ...; the waves' count changes meet in LDS, wave 0 decides and commits.  With few chains per GPU (the
+//    per-GPU shares of the 8-GPU configs: 1024, 256 chains) this is what keeps the chip busy: a move's ~6 pair
+//    evaluations run side by side instead of one after the other.  (With 4096 chains one wave per chain already fills
+//    the 4 waves per SIMD that 128 VGPRs allow, and W = 1.)
+//  * The chain's context lives in LDS; the proposal itself (clique_setup) and the simple moves (20 % of the default
+//    mix; the multi-wave kernel's exact run, mw_exact_call) are out-of-line calls made by wave 0.
 //
-// Local sets beyond 64 vertices, split graphs that do not fit 64 nodes and local sets of 257..1024 vertices take the
-// wide / workspace evaluators pair by pair, with the same patches applied to their masks.
+// Local sets beyond 64 vertices, split graphs that do not fit 64 nodes and local sets of 257..1024 vertices are left to
+// wave 0, which takes them one by one on the wide / workspace evaluators with the same patches set into their masks.
 #pragma once
-#include <type_traits>
 
-// tallies: the OT_* words of the one-wave kernel (fcm_kernels_common.hpp)
-#define CQ_TALLY_WORDS 8u   // u64 words: OT_* (12 u32), then the last setup's nchg, npairs, status, n_d
+// LDS map in u64 words (W = waves per chain):
+//   the multi-wave kernel's layout for ONE wave (its table fill and exact run are called as they are, by wave 0):
+//     shared words | ring (record 0 = where a simple move's exact run leaves its record) | wave 0: Hp, arc list, draw table, tallies | wide evaluator
+//   tables (clique buckets, order thresholds) | tallies + the setup's scalars | dix | deferred pairs | per-wave sums [W][16] | clique arrays
+//   | Hp + arc list of the waves 1 .. W-1
+#define CQ_TALLY_WORDS 8u   // OT_* (12 u32), then the last setup's nchg, npairs, status, n_d
 #define CQ_ORDERS 8         // clique orders the kernel takes (<= 8 count entries means cliques of <= 8 vertices)
-#define CQ_TABLE_WORDS (4u * CQ_ORDERS + 4u)   // u64 words: cl_base | cl_count | clp_base | cumo | clq, clq_pairs, (cl_orders, chg_cap), spare
-__host__ __device__ constexpr inline unsigned fcm_cq_lds_words(int NW, unsigned chg_cap)
+#define CQ_TABLE_WORDS (4u * CQ_ORDERS + 4u)   // cl_base | cl_count | clp_base | cumo | clq, clq_pairs, (cl_orders, chg_cap), spare
+#define CQ_DIX_WORDS 128u   // one byte per vertex of a graph of <= 1024 vertices: its index in d, plus one
+#define CQ_DEFER_WORDS 34u  // [0]: number of deferred pairs (u32), then up to 128 pair indices (u16)
+#define CQ_PSUM_WORDS 16u   // per wave: 16 x i32 count changes, then status, sum_k, spare x 2 ... (32 u32)
+#define CQ_MAXW 8u
+__host__ __device__ constexpr inline unsigned fcm_cq_lds_words(int NW, unsigned chg_cap, unsigned W)
 {
-    return fcm_mw_lds_words(NW, 1) + fcm_clique_lds_words(chg_cap) + CQ_TALLY_WORDS + CQ_TABLE_WORDS;
+    return fcm_mw_lds_words(NW, 1) + CQ_TABLE_WORDS + CQ_TALLY_WORDS + CQ_DIX_WORDS + CQ_DEFER_WORDS + W * CQ_PSUM_WORDS + fcm_clique_lds_words(chg_cap)
+           + (W - 1u) * 128u;
 }
 struct CqLds {
     u64 *mine, *wide, *tables;
-    u32 *tly;
+    u32 *tly, *defer, *psum;
+    unsigned char *dix;
     CliqueLds CL;
+    u64 *hp_more;     // Hp + arc list of wave w >= 1 at hp_more + (w - 1) * 128
 };
-// (the tables and the tallies in front of the clique arrays: their place does not depend on the pair list's capacity)
-__device__ __forceinline__ CqLds cq_carve(u64 *smem, int maxnw)
+// (everything whose place does not depend on the pair list's capacity comes first; W from the launch)
+__device__ __forceinline__ CqLds cq_carve(u64 *smem, int maxnw, u32 W, u32 chg_cap)
 {
     CqLds L;
     L.mine = smem + MW_SHARED_WORDS + MW_RING_WORDS(1u);
     L.wide = L.mine + MW_WAVE_WORDS;
     L.tables = L.wide + fcm_lds_words(maxnw);
     L.tly = (u32 *)(L.tables + CQ_TABLE_WORDS);
-    L.CL = clique_carve(L.tables + CQ_TABLE_WORDS + CQ_TALLY_WORDS);
+    L.dix = (unsigned char *)(L.tables + CQ_TABLE_WORDS + CQ_TALLY_WORDS);
+    L.defer = (u32 *)(L.tables + CQ_TABLE_WORDS + CQ_TALLY_WORDS + CQ_DIX_WORDS);
+    L.psum = (u32 *)(L.tables + CQ_TABLE_WORDS + CQ_TALLY_WORDS + CQ_DIX_WORDS + CQ_DEFER_WORDS);
+    u64 *cl = L.tables + CQ_TABLE_WORDS + CQ_TALLY_WORDS + CQ_DIX_WORDS + CQ_DEFER_WORDS + W * CQ_PSUM_WORDS;
+    L.CL = clique_carve(cl);
+    L.hp_more = cl + fcm_clique_lds_words(chg_cap);
     return L;
 }
 enum { CS_NCHG = 12, CS_NPAIRS, CS_STATUS, CS_ND };   // u32 words of the tally block the setup leaves its scalars in
+enum { PS_STATUS = 16, PS_SUMK = 17 };               // u32 words of a wave's sums behind its 16 count changes
 
-// ---- out of line: the proposal of a clique move (clique_setup) with its context from LDS; what it finds goes to the
-// clique arrays (pair list in CL.chg, d in CL.d, the in-masks over d before / after the move in CL.oldm / CL.newm) and
-// to the CS_* words.
-__device__ __attribute__((noinline)) void cq_setup_call(u64 *smem, u32 tv, u32 q)
+// ---- out of line (wave 0): the proposal of a clique move (clique_setup) with its context from LDS; what it finds goes
+// to the clique arrays (pair list in CL.chg, d in CL.d, the in-masks over d before / after the move in CL.oldm / CL.newm)
+// and to the CS_* words.
+__device__ __attribute__((noinline)) void cq_setup_call(u64 *smem, u32 tv, u32 q, u32 W)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    q = mw_uni(q);
+    q = mw_uni(q); W = mw_uni(W);
     const u32 *ctx = (const u32 *)(smem + MW_CTX_OFF);
     const u32 cv = lane < MC_WORDS ? ctx[lane] : 0u;
     const int maxnw = (int)rdlane(cv, MC_MAXNW);
-    const CqLds L = cq_carve(smem, maxnw);
-    const u64 oc = mw_uni64(L.tables[4 * CQ_ORDERS + 2]);
+    const u64 oc = mw_uni64((smem + MW_SHARED_WORDS + MW_RING_WORDS(1u) + MW_WAVE_WORDS + fcm_lds_words(maxnw))[4 * CQ_ORDERS + 2]);
     const u32 chg_cap = (u32)(oc >> 32);
+    const CqLds L = cq_carve(smem, maxnw, W, chg_cap);
     const MwChain C = mw_chain_from_lds(ctx, lane);
     const u64 seed = (u64)rdlane(cv, MC_SEED) | ((u64)rdlane(cv, MC_SEED + 1) << 32);
     const u64 sampled0 = (u64)rdlane(cv, MC_SAMPLED0) | ((u64)rdlane(cv, MC_SAMPLED0 + 1) << 32);
@@ -76,53 +94,8 @@ __device__ __attribute__((noinline)) void cq_setup_call(u64 *smem, u32 tv, u32 q
     const CliqueResult cr = clique_setup(T, C.rows, L.CL, move, w1, x64, sampled0 + q, rdlane(cv, MC_GCHAIN), (u32)seed, (u32)(seed >> 32), lane, nullptr, nullptr);
     wave_sync();
     if (lane < 32) { L.CL.oldm[lane] = cr.oldt; L.CL.newm[lane] = cr.newt; }   // (the rows themselves are not needed any more)
-    if (lane == 0) { L.tly[CS_NCHG] = (u32)cr.nchg; L.tly[CS_NPAIRS] = (u32)cr.npairs; L.tly[CS_STATUS] = cr.status; L.tly[CS_ND] = (u32)cr.n_d; }
+    if (lane == 0) { L.tly[CS_NCHG] = (u32)cr.nchg; L.tly[CS_NPAIRS] = (u32)cr.npairs; L.tly[CS_STATUS] = cr.status; L.tly[CS_ND] = (u32)cr.n_d; L.defer[0] = 0u; }
     wave_sync();
-}
-
-// ---- whole-row build, split into its two halves for pipelining (n <= 1024: rows of one cache line) -------------------
-// issue: 24 loads, always -- rows beyond the list re-read the row of its last vertex (the list's lanes beyond s repeat
-// `small`), a line the cache holds: a fixed number of loads in flight keeps the compiler's s_waitcnt counts static
-template <int Q = 0>
-__device__ __forceinline__ void cq_issue_rows(const rsrc_t rsrc, u32 Lv, u32 sel, u32 dw, u32 (&w)[24])
-{
-    if constexpr (Q < 24) {
-        const u32 v = (u32)__builtin_amdgcn_ds_bpermute((int)(sel + 8u * Q), (int)Lv);
-        w[Q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (v << 7) + dw, 0, 0);
-        cq_issue_rows<Q + 1>(rsrc, Lv, sel, dw, w);
-    }
-}
-// consume: rows 0..47 of the local adjacency (those below s); rows 48..63 in a second trip of their own
-__device__ __forceinline__ u64 cq_consume_rows(const rsrc_t rsrc, const u32 (&w)[24], u32 Lv, u32 sel, u32 dw, int s, int lane)
-{
-    const u32 src = (Lv >> 5) * 4u, bpos = Lv & 31u;
-    u32 hlo = 0u, hhi = 0u;
-    build128_consume<0, 0, 6, 24>(w, src, bpos, s, hlo, hhi);
-    if (s > 48) {
-        u32 w2[8];
-        build_regs_any(w2);
-        build128_issue<6, 6, 8, 8>(rsrc, Lv, sel, dw, s, w2);
-        build128_consume<6, 6, 8, 8>(w2, src, bpos, s, hlo, hhi);
-    }
-    const u64 h = (u64)hlo | ((u64)hhi << 32);
-    return lane < s ? (h & (s >= 64 ? ~0ull : ((1ull << s) - 1ull))) : 0ull;
-}
-
-// The rows in flight are carried around the pair loop as 24 separate scalars: carried as an array, hipcc's SROA turns
-// them into ONE 24-element vector value (a 32-register tuple with a phi at the loop head) and every element write
-// copies the tuple through scratch.
-struct CqRows { u32 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, a16, a17, a18, a19, a20, a21, a22, a23; };
-__device__ __forceinline__ void cq_rows_get(const CqRows &r, u32 (&w)[24])
-{
-    w[0] = r.a0; w[1] = r.a1; w[2] = r.a2; w[3] = r.a3; w[4] = r.a4; w[5] = r.a5; w[6] = r.a6; w[7] = r.a7;
-    w[8] = r.a8; w[9] = r.a9; w[10] = r.a10; w[11] = r.a11; w[12] = r.a12; w[13] = r.a13; w[14] = r.a14; w[15] = r.a15;
-    w[16] = r.a16; w[17] = r.a17; w[18] = r.a18; w[19] = r.a19; w[20] = r.a20; w[21] = r.a21; w[22] = r.a22; w[23] = r.a23;
-}
-__device__ __forceinline__ void cq_rows_put(CqRows &r, const u32 (&w)[24])
-{
-    r.a0 = w[0]; r.a1 = w[1]; r.a2 = w[2]; r.a3 = w[3]; r.a4 = w[4]; r.a5 = w[5]; r.a6 = w[6]; r.a7 = w[7];
-    r.a8 = w[8]; r.a9 = w[9]; r.a10 = w[10]; r.a11 = w[11]; r.a12 = w[12]; r.a13 = w[13]; r.a14 = w[14]; r.a15 = w[15];
-    r.a16 = w[16]; r.a17 = w[17]; r.a18 = w[18]; r.a19 = w[19]; r.a20 = w[20]; r.a21 = w[21]; r.a22 = w[22]; r.a23 = w[23];
 }
 
 // ---- the earlier pairs' changes, XORed into the local in-masks ------------------------------------------------------
@@ -131,29 +104,34 @@ __device__ __forceinline__ void cq_rows_put(CqRows &r, const u32 (&w)[24])
 // lane t's in-masks over d (bit u = d[u] -> d[t]) before and after the whole move; dvv: d[lane].
 // For every d-vertex u that is in the list: the lanes of the d-vertices t whose edge u -> t changed before x flip bit
 // pos(u).
-__device__ __forceinline__ u64 cq_patch(u64 myH, u32 Lv, int s, u32 dvv, u32 oldt, u32 newt, int n_d, int xi, int xj, int lane)
+// dix (graphs of <= 1024 vertices): LDS table vertex -> index in d plus one, 0 for the vertices not in d; null otherwise.
+__device__ __forceinline__ u64 cq_patch(u64 myH, u32 Lv, int s, u32 dvv, u32 oldt, u32 newt, int n_d, int xi, int xj, int lane, const unsigned char *dix)
 {
     // chg_in[t]: bits u with (pair {t,u} before x) and (edge u -> t changed)
     const u32 lt_i = (1u << xi) - 1u, lt_j = (1u << xj) - 1u;
     const u32 M = lane < xi ? 0xFFFFFFFFu : (lane == xi ? lt_j : (lt_i | (lane < xj ? (1u << xi) : 0u)));
     const u32 chg_in = (oldt ^ newt) & M;
     if (ballot(chg_in != 0u) == 0ull) return myH;                 // nothing before x changed (always so for the first pair)
-    // tj: this lane's d index, 32 if its vertex is not in d; pos: lane u <- the list position of d[u] | 0x100
+    // tj: this lane's d index, 32 or more if its vertex is not in d (lanes beyond the list repeat its last vertex: not theirs)
     u32 tj = 32u;
-    for (int u = 0; u < n_d; ++u) tj = (lane < s && Lv == rdlane(dvv, u)) ? (u32)u : tj;
-    const u32 posv = (u32)__builtin_amdgcn_ds_permute((int)((tj < 32u ? tj : 63u) * 4u), (int)((u32)lane | 0x100u));
+    if (dix) {
+        tj = lane < s ? (u32)dix[Lv] - 1u : 32u;
+    } else {
+        for (int u = 0; u < n_d; ++u) tj = (lane < s && Lv == rdlane(dvv, u)) ? (u32)u : tj;
+    }
+    const bool isd = tj < 32u;
+    // posv: lane u <- the list position of d[u] | 0x100 (lanes that are no d-vertex send to lane 63: n_d <= 32)
+    const u32 posv = (u32)__builtin_amdgcn_ds_permute((int)((isd ? tj : 63u) * 4u), (int)((u32)lane | 0x100u));
     // this lane's changes as a target, fetched from lane tj
+    // (every lane takes part: ds_bpermute reads nothing from a lane that is masked off)
     const u32 mine = (u32)__builtin_amdgcn_ds_bpermute((int)((tj & 31u) * 4u), (int)chg_in);
-    u32 xlo = 0u, xhi = 0u;
+    u64 X = 0ull;
     for (int u = 0; u < n_d; ++u) {
         const u32 pu = rdlane(posv, u);
         if (!(pu & 0x100u)) continue;                             // d[u] is not in this pair's local set: no simplex through the pair holds it
-        const u32 b = __builtin_amdgcn_ubfe(mine, (u32)u, 1u);
-        const u32 pos = pu & 63u;
-        if (pos < 32u) xlo |= b << pos; else xhi |= b << (pos - 32u);
+        X |= (u64)__builtin_amdgcn_ubfe(mine, (u32)u, 1u) << (pu & 63u);
     }
-    const bool isd = tj < 32u;
-    return myH ^ (isd ? ((u64)xlo | ((u64)xhi << 32)) : 0ull);
+    return myH ^ (isd ? X : 0ull);
 }
 
 // per-pair scalars, read off the pair list (lane x of the chunk holds pair x)
@@ -271,11 +249,6 @@ __device__ __forceinline__ void cq_commit(u32 *rows, u32 stride32, const CliqueL
     wave_sync();
 }
 
-struct CqEval {
-    u64 sum_k;
-    u32 status, n_wide, any_wide, any_xw;
-};
-
 // one pair on the fast evaluator: classes around (big, small) from the patched in-masks, one evaluation per changed
 // direction.  Returns false if the split graph of a needed direction does not fit 64 nodes.
 template <int MAXT>
@@ -304,20 +277,16 @@ __device__ __forceinline__ bool cq_eval_pair(u64 myH, u64 *Hp, const CqPair &P, 
     return true;
 }
 
-// All changed pairs of a clique move (CL.chg, npairs of them), on the pre-move bitmap.
-template <int MAXT, bool ROWS128, bool XW>
-__device__ __forceinline__ CqEval cq_pairs(const MwChain &C, u64 *Hp, u64 *wide_lds, int maxnw, const CliqueLds CL, int npairs, int n_d,
-                                           int lane, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard)
+// This wave's share of the changed pairs of a clique move (CL.chg, npairs of them): pairs wv, wv + W, ..., each on the
+// pre-move bitmap.  Pairs the fast evaluator does not take are put on the deferred list (wave 0 takes them afterwards).
+template <int MAXT>
+__device__ __forceinline__ void cq_pairs(const MwChain &C, u64 *Hp, const CliqueLds CL, const unsigned char *dix, u32 *defer, int npairs, int n_d, u32 wv, u32 W,
+                                         int lane, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard, u32 &status, u32 &sum_k)
 {
-    CqEval R = {0ull, 0u, 0u, 0u, 0u};
     const int tmax = MAXT;
     const rsrc_t rr = make_rows_rsrc(C.rows, C.rows_bytes);
-    const u32 stride32 = ROWS128 ? 32u : C.stride32;
     const u32 dvv = lane < n_d ? CL.d[lane] : 0xFFFFFFFFu;
     const u32 oldt = lane < 32 ? CL.oldm[lane] : 0u, newt = lane < 32 ? CL.newm[lane] : 0u;   // in-masks over d before / after the move (cq_setup_call)
-    u32 sel = lane >= 32 ? 4u : 0u;
-    asm volatile("" : "+v"(sel));
-    const u32 dw = (u32)(lane & 31) * 4u;
     for (int base = 0; base < npairs; base += WAVE) {
         const int cnt = min(WAVE, npairs - base);
         // lane x of the chunk: pair base + x
@@ -327,94 +296,64 @@ __device__ __forceinline__ CqEval cq_pairs(const MwChain &C, u64 *Hp, u64 *wide_
             pw0 = c.x; pk = c.z; poff = c.w;
             pa = CL.d[c.x & 0xFFu]; pb = CL.d[(c.x >> 8) & 0xFFu];
         }
-        auto slow = [&](const CqPair &P, int x) {
-            const u32 dirs = P.o_bs | (P.o_sb << 1) | (P.n_bs << 2) | (P.n_sb << 3);
-            if (!R.any_wide) {
-                const Wide W = wide_carve(wide_lds, maxnw);
-                wide_zero_counts(W, lane);
-                if (XW && C.xw) { if (lane < 16) xw_carve(C.xw, 64).cnt[lane] = 0; xw_sync(); }
-                R.any_wide = 1u;
-            }
-            if (P.k + 2 > 64 * maxnw) R.any_xw = 1u;
-            R.status |= cq_wide_pair<XW>(wide_lds, maxnw, C.xw, C.rows, stride32, C.nb, CL, base + x, P.big, P.small, P.off, P.k, dirs, tmax);
-            R.n_wide += 1u;
+        // this wave's pairs of the chunk; the list of the next one is requested before the current one is evaluated
+        auto list_of = [&](int x) -> u32 {
+            const CqPair P = cq_pair_at(pw0, pk, poff, pa, pb, x);
+            return P.k + 2 <= WAVE ? load_list(C.nb, P.off, P.k, P.big, P.small, lane) : 0u;
         };
-        auto tally_k = [&](const CqPair &P) { R.sum_k += (u64)P.k * (u64)((P.o_bs != P.n_bs ? 1 : 0) + (P.o_sb != P.n_sb ? 1 : 0)); };
-        if constexpr (ROWS128) {
-            // Software pipeline, one row buffer: as soon as pair x's rows have been consumed, the rows of pair x+1 are
-            // requested into the same registers and the list of pair x+2 after them; both round trips run behind pair x's
-            // patches and evaluations.  Every load outstanding when a pair's rows are waited for was issued a whole
-            // evaluation phase earlier.
-            CqRows rows_in_flight;
-            // (pair data is read off the lanes where it is needed, not carried around the loop in SGPRs)
-            auto list_of = [&](int x) -> u32 {
-                const CqPair P = cq_pair_at(pw0, pk, poff, pa, pb, x);
-                return P.k + 2 <= WAVE ? load_list(C.nb, P.off, P.k, P.big, P.small, lane) : 0u;
-            };
-            u32 Lvc = list_of(0), Lvn = cnt > 1 ? list_of(1) : 0u;
-            { u32 w[24]; cq_issue_rows(rr, Lvc, sel, dw, w); cq_rows_put(rows_in_flight, w); }
+        const int x0 = (int)((wv + W - ((u32)base % W)) % W);   // (pairs are dealt by their index in the whole list)
+        u32 Lvn = x0 < cnt ? list_of(x0) : 0u;
 #pragma nounroll
-            for (int x = 0; x < cnt; ++x) {
-                const int kc = (int)rdlane(pk, x);
-                const bool fast = kc + 2 <= WAVE;
-                u64 myH = 0ull;
-                { u32 w[24]; cq_rows_get(rows_in_flight, w); if (fast) myH = cq_consume_rows(rr, w, Lvc, sel, dw, kc + 2, lane); }
-                if (x + 1 < cnt) { u32 w[24]; cq_issue_rows(rr, Lvn, sel, dw, w); cq_rows_put(rows_in_flight, w); }   // rows of pair x+1 (its list came in during the last evaluations)
-                const u32 Lvnn = x + 2 < cnt ? list_of(x + 2) : 0u;                                                      // list of pair x+2
-                const CqPair Pc = cq_pair_at(pw0, pk, poff, pa, pb, x);
-                tally_k(Pc);
-                bool done = false;
-                if (fast) {
-                    myH = cq_patch(myH, Lvc, kc + 2, dvv, oldt, newt, n_d, Pc.xi, Pc.xj, lane);
-                    done = cq_eval_pair<MAXT>(myH, Hp, Pc, tmax, lane, delta, es, guard, R.status);
-                }
-                if (!done) slow(Pc, x);
-                Lvc = Lvn; Lvn = Lvnn;
+        for (int x = x0; x < cnt; x += (int)W) {
+            const u32 Lv = Lvn;
+            const CqPair P = cq_pair_at(pw0, pk, poff, pa, pb, x);
+            sum_k += (u32)P.k * (u32)((P.o_bs != P.n_bs ? 1 : 0) + (P.o_sb != P.n_sb ? 1 : 0));
+            bool done = false;
+            if (P.k + 2 <= WAVE) {
+                u64 myH = build_local(rr, C.stride32, Lv, P.k + 2, lane);
+                if (x + (int)W < cnt) Lvn = list_of(x + (int)W);
+                myH = cq_patch(myH, Lv, P.k + 2, dvv, oldt, newt, n_d, P.xi, P.xj, lane, dix);
+                done = cq_eval_pair<MAXT>(myH, Hp, P, tmax, lane, delta, es, guard, status);
+            } else if (x + (int)W < cnt) {
+                Lvn = list_of(x + (int)W);
             }
-        } else {
-            for (int x = 0; x < cnt; ++x) {
-                const CqPair P = cq_pair_at(pw0, pk, poff, pa, pb, x);
-                tally_k(P);
-                bool done = false;
-                if (P.k + 2 <= WAVE) {
-                    const u32 Lv = load_list(C.nb, P.off, P.k, P.big, P.small, lane);
-                    u64 myH = build_local_loop16(rr, stride32, Lv, P.k + 2, lane);
-                    myH = cq_patch(myH, Lv, P.k + 2, dvv, oldt, newt, n_d, P.xi, P.xj, lane);
-                    done = cq_eval_pair<MAXT>(myH, Hp, P, tmax, lane, delta, es, guard, R.status);
-                }
-                if (!done) slow(P, x);
+            if (!done && lane == 0) {
+                const u32 at = atomicAdd(&defer[0], 1u);
+                ((unsigned short *)(defer + 1))[at & 127u] = (unsigned short)(base + x);
             }
         }
     }
-    return R;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MAXT, bool ROWS128, bool XW>
+template <int MAXT>
 __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
 {
     const int lane = threadIdx.x & (WAVE - 1);
+    const u32 wv = mw_uni(threadIdx.x >> 6);
+    const u32 W = p.mw_waves >= 2 ? p.mw_waves : 1u;       // waves of this chain's workgroup (blockDim.x / 64)
     const u32 chain = blockIdx.x;
     const u32 N = (u32)p.nprop;
     if (N == 0) return;
     const int maxnw = p.maxnw < 2 ? 2 : p.maxnw;
 
-    // the multi-wave kernel's LDS layout with W = 1 (its table fill and exact run are called as they are), then the
-    // clique move's arrays and this kernel's tallies
     u64 *ent = smem;                                       // E[i] = {count i, flag, bmin i, bmax i}
     u32 *ctl = (u32 *)(smem + MW_HEAD_OFF);
     u32 *ctx = (u32 *)(smem + MW_CTX_OFF);
     u32 *vis = (u32 *)(smem + MW_VIS_OFF);
     u32 *stage = (u32 *)(smem + MW_SHARED_WORDS);          // record 0 of the ring: where a simple move's exact run leaves its record
-    const CqLds L = cq_carve(smem, maxnw);
+    const CqLds L = cq_carve(smem, maxnw, W, p.chg_cap);
     u64 *mine_lds = L.mine;
-    u64 *Hp = mine_lds;
+    u64 *Hp = wv == 0 ? mine_lds : L.hp_more + (size_t)(wv - 1u) * 128u;
     const u32 *T = (const u32 *)(mine_lds + 128);
     u64 *wide_lds = L.wide;
     const CliqueLds CL = L.CL;
     u32 *tly = L.tly;
+    u32 *my_psum = L.psum + (size_t)wv * 32u;
+    const unsigned char *dix = p.n <= 1024u ? L.dix : nullptr;
     u64 *st_g = (u64 *)p.stats + (size_t)chain * FCM_DEV_NSTATS;
     u64 *cnt_g = (u64 *)p.counts + (size_t)chain * FCM_DEV_MAX_COUNTS;
+    auto barrier = [&]() { if (W > 1u) mw_barrier(); };
 
     MwChain C;
     C.rows = p.rows + (size_t)chain * p.rows_per_chain;
@@ -425,7 +364,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
     C.U = p.U; C.D = p.D; C.stride32 = p.stride32;
     u32 *slot_of = p.slot_of + (size_t)chain * p.U;
     const u64 sampled0 = st_g[0];
-    {
+    if (wv == 0) {
         const int NC = p.ncounts;
         const bool cl = lane < NC;
         const u64 c0 = cl ? cnt_g[lane] : 0ull;
@@ -434,6 +373,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
         if (lane < 9) { ent[lane * 4 + 0] = c0; ent[lane * 4 + 1] = (lane == 0 && inb) ? 1ull : 0ull; ent[lane * 4 + 2] = mn; ent[lane * 4 + 3] = mx; }
         if (lane < 16) vis[lane] = MW_NONE;
         if (lane < 16) tly[lane] = 0u;
+        for (u32 i = (u32)lane; i < CQ_DIX_WORDS; i += WAVE) ((u64 *)L.dix)[i] = 0ull;
         if (lane == 0) {
             ctl[0] = 0u;
             *(smem + MW_TALLY_OFF) = 0ull;
@@ -442,8 +382,9 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
             *(u64 *)(ctx + MC_SAMPLED0) = sampled0;
             *(u64 *)(ctx + MC_CUM0) = p.cum0; *(u64 *)(ctx + MC_CUM1) = p.cum1; *(u64 *)(ctx + MC_CUM2) = p.cum2;
             ctx[MC_U] = C.U; ctx[MC_D] = C.D; ctx[MC_STRIDE32] = C.stride32; ctx[MC_GCHAIN] = p.first_chain + chain;
-            ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = 1u; *(u64 *)(ctx + MC_GUARD) = p.guard_limit; *(u64 *)(ctx + MC_XW) = (u64)C.xw;
-            L.tables[4 * CQ_ORDERS] = (u64)p.clq; L.tables[4 * CQ_ORDERS + 1] = (u64)p.clq_pairs; L.tables[4 * CQ_ORDERS + 2] = (u64)(u32)p.cl_orders | ((u64)p.chg_cap << 32);
+            ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = 1u; *(u64 *)(ctx + MC_GUARD) = p.guard_limit; *(u64 *)(ctx + MC_XW) = (u64)C.xw;   // (MC_W = 1: the exact run's own layout)
+            L.tables[4 * CQ_ORDERS] = (u64)p.clq; L.tables[4 * CQ_ORDERS + 1] = (u64)p.clq_pairs;
+            L.tables[4 * CQ_ORDERS + 2] = (u64)(u32)p.cl_orders | ((u64)p.chg_cap << 32);
         }
         if (lane < CQ_ORDERS) {
             L.tables[lane] = p.cl_base[lane]; L.tables[CQ_ORDERS + lane] = p.cl_count[lane];
@@ -451,16 +392,21 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
         }
         wave_sync();
     }
+    barrier();
     FcmGuard guard = {MAXT >= 6 ? p.guard_limit : 0x7FFFFFFFull, 0u};
     u32 ti = MW_TBL_N;
 
     for (u32 q = 0; q < N; ++q) {
-        if (ti >= MW_TBL_N) { mw_fill_table(smem, 0u, q); ti = 0u; }
+        if (ti >= MW_TBL_N) {
+            if (wv == 0) mw_fill_table(smem, 0u, q);
+            barrier();
+            ti = 0u;
+        }
         const u32 tv = lane < (int)MW_TBL_WORDS ? T[ti * MW_TBL_WORDS + lane] : 0u;
         ++ti;
         const int move = (int)(rdlane(tv, 0) & 0xFFu);
 
-        // what the decision needs, from either kind of move
+        // what wave 0's decision needs, from either kind of move
         int myd = 0;                       // lane d: the change of count[d]
         long long wide_d = 0;              // ... its share that came through a 64-bit evaluator
         u32 nonempty = 0u, pst = 0u;
@@ -469,24 +415,35 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
         u32 sv = 0u, w_clr = 0u, w_set = 0u;
 
         if (move < 2) {
-            // ---- single_edge_flip / double_edge_move (src/lib.rs:292-325): the multi-wave kernel's exact run, out of line
-            mw_exact_call<MAXT, ROWS128>(smem, 0u, tv, q, (u32)(stage - (u32 *)smem));
-            const u32 *out = (const u32 *)(mine_lds + 64);
-            const u32 xv = lane < 18 ? out[lane] : 0u;
-            myd = lane < 16 ? (int)xv : 0;
-            w_clr = rdlane(xv, 16); w_set = rdlane(xv, 17);
-            sv = lane < SR_WORDS ? stage[lane] : 0u;
-            wave_sync();
-            const u32 flg = rdlane(sv, SR_FLAGS);
-            nonempty = flg & SRF_NONEMPTY;
-            pst = rdlane(sv, SR_SUS);
-            t_sumk = (flg >> 8) & 0xFFFu; t_wide = (flg >> 2) & 1u; t_big = (flg >> 3) & 1u;
-            if (nonempty) kind = (flg & SRF_DMOVE) ? (1u << OT_DMOVE) : (1u << OT_FLIP);
+            // ---- single_edge_flip / double_edge_move (src/lib.rs:292-325): wave 0, the multi-wave kernel's exact run, out of line
+            if (wv == 0) {
+                if (C.stride32 == 32u) mw_exact_call<MAXT, true>(smem, 0u, tv, q, (u32)(stage - (u32 *)smem));   // rows of one cache line: the whole-row build
+                else mw_exact_call<MAXT, false>(smem, 0u, tv, q, (u32)(stage - (u32 *)smem));
+                const u32 *out = (const u32 *)(mine_lds + 64);
+                const u32 xv = lane < 18 ? out[lane] : 0u;
+                myd = lane < 16 ? (int)xv : 0;
+                w_clr = rdlane(xv, 16); w_set = rdlane(xv, 17);
+                sv = lane < SR_WORDS ? stage[lane] : 0u;
+                wave_sync();
+                const u32 flg = rdlane(sv, SR_FLAGS);
+                nonempty = flg & SRF_NONEMPTY;
+                pst = rdlane(sv, SR_SUS);
+                t_sumk = (flg >> 8) & 0xFFFu; t_wide = (flg >> 2) & 1u; t_big = (flg >> 3) & 1u;
+                if (nonempty) kind = (flg & SRF_DMOVE) ? (1u << OT_DMOVE) : (1u << OT_FLIP);
+            }
         } else {
             // ---- clique_permute / clique_swap (src/lib.rs:214-290)
-            cq_setup_call(smem, tv, q);
+            if (wv == 0) {
+                cq_setup_call(smem, tv, q, W);
+                if (dix) {   // vertex -> index in d, for the patches (put back to zero after the decision)
+                    const u32 nd = tly[CS_ND];
+                    if (tly[CS_NCHG] && lane < (int)nd) L.dix[CL.d[lane]] = (unsigned char)(lane + 1);
+                    wave_sync();
+                }
+            }
+            barrier();                                                           // the pair list is there
             const u32 csv = lane < 16 ? tly[lane] : 0u;
-            const int nchg = (int)rdlane(csv, CS_NCHG);
+            const int nchg = (int)rdlane(csv, CS_NCHG), n_d = (int)rdlane(csv, CS_ND);
             pst = rdlane(csv, CS_STATUS);
             if (nchg > 0) {
                 nonempty = 1u;
@@ -496,10 +453,10 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
 #pragma unroll
                 for (int t = 0; t <= MAXT; ++t) delta[t] = 0;
                 EvScal es = {0, 0};
-                const CqEval ev = cq_pairs<MAXT, ROWS128, XW>(C, Hp, wide_lds, maxnw, CL, npairs, (int)rdlane(csv, CS_ND), lane, delta, es, &guard);
-                pst |= ev.status;
-                t_sumk = (u32)ev.sum_k; t_changes = (u32)nchg; t_wide = ev.n_wide;
+                u32 my_status = 0u, my_sumk = 0u;
+                cq_pairs<MAXT>(C, Hp, CL, dix, L.defer, npairs, n_d, wv, W, lane, delta, es, &guard, my_status, my_sumk);
                 fcm_lane_guard<MAXT>(delta, guard);
+                if (guard.tripped) my_status |= 256u;                            // a local count may have passed 2^31: refuse rather than wrap
                 myd = lane_in(4ull) ? es.d1 : 0;
                 if (MAXT >= 2) myd = lane_in(8ull) ? es.d2 : myd;
 #pragma unroll
@@ -507,73 +464,122 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
                     const int sum = wave_sum_i32(delta[tq]);
                     myd = lane_in(1ull << (tq + 1)) ? sum : myd;
                 }
-                if (ev.any_wide) {
-                    const Wide W = wide_carve(wide_lds, maxnw);
-                    if (lane >= 2 && lane < 16 && lane - 1 <= MAXT) wide_d = W.cnt[lane - 1];
-                    if (XW && ev.any_xw && lane >= 2 && lane < 16 && lane - 1 <= MAXT) wide_d += xw_count(C.xw, lane - 1);
-                    wave_sync();
+                if (W > 1u) {                                                    // the waves' shares meet in LDS
+                    if (lane < 16) my_psum[lane] = (u32)myd;
+                    if (lane == 0) { my_psum[PS_STATUS] = my_status; my_psum[PS_SUMK] = my_sumk; }
+                    barrier();
+                    if (wv == 0) {
+                        long long tot = 0;
+                        u32 st = 0u, sk = 0u;
+                        for (u32 w = 0; w < W; ++w) {
+                            tot += lane < 16 ? (long long)(int)L.psum[w * 32u + (u32)lane] : 0ll;
+                            st |= L.psum[w * 32u + PS_STATUS]; sk += L.psum[w * 32u + PS_SUMK];
+                        }
+                        myd = 0; wide_d = tot;                                   // (64-bit: W sums of 32-bit wave sums)
+                        my_status = st; my_sumk = sk;
+                    }
                 }
-            }
-        }
-
-        // ---- sampled += 1; Bounds::check; accept or drop (src/lib.rs:185-191)
-        const u32 eoff = (u32)min(lane, 8) * 32u;
-        const uint4 dyn = *(const uint4 *)((const char *)ent + eoff);
-        const uint4 stat = *(const uint4 *)((const char *)ent + eoff + 16u);
-        const u64 bmin = (u64)stat.x | ((u64)stat.y << 32), bmax = (u64)stat.z | ((u64)stat.w << 32);
-        const u64 cnt = (u64)dyn.x | ((u64)dyn.y << 32);
-        const u32 in_bounds = rdlane(dyn.z, 0);
-        const u64 ncnt = cnt + (u64)((long long)myd + wide_d);
-        const u64 outside = ballot(ncnt < bmin) | ballot(ncnt > bmax);
-        const u32 commit = outside == 0ull ? nonempty : 0u;
-        if (nonempty && (ballot((long long)ncnt < 0) & 0xFFull)) pst |= 8u;   // reference assert, src/lib.rs:65 (counts stay far below 2^63)
-        // flag_count grows to post's length when the transition is applied, accepted or not, and never shrinks (src/lib.rs:72-74, 89-91)
-        const u32 nzm = nonempty ? (u32)(ballot(ncnt != 0ull) & 0xFFull) : 0u;
-        if (commit) {
-            if (lane < 8) ent[lane * 4] = ncnt;
-            if (lane == 0 && !in_bounds) ent[1] = 1ull;
-            if (move >= 2) {
-                cq_commit(C.rows, C.stride32, CL, npairs, lane);
-                pst |= clique_update_slots(C.dbl, slot_of, CL, npairs, lane);
-            } else {
-                const u32 flg = rdlane(sv, SR_FLAGS);
-                const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
-                const u32 bit_clr = 1u << ((flg >> 20) & 31u), bit_set = 1u << ((flg >> 25) & 31u);
-                u32 nclr = w_clr & ~bit_clr, nset = w_set | bit_set;
-                if (wid_clr == wid_set) { nclr |= bit_set; nset = nclr; }
-                if (lane == 0) {
-                    C.rows[wid_clr] = nclr;
-                    C.rows[wid_set] = nset;
-                    if (flg & SRF_DMOVE) {   // the slot's pair stops being reciprocal, the single edge's pair becomes so
-                        const u32 slot = rdlane(sv, SR_DSLOT), was = rdlane(sv, SR_ID1), now = rdlane(sv, SR_ID2);
-                        slot_of[was] = FCM_NOSLOT;
-                        slot_of[now] = slot;
-                        C.dbl[slot] = now;
+                if (wv == 0) {
+                    pst |= my_status;
+                    t_sumk = my_sumk; t_changes = (u32)nchg;
+                    // the pairs left over for the wide evaluators, one by one
+                    const u32 ndefer = mw_uni(L.defer[0]);
+                    if (ndefer) {
+                        const Wide Wd = wide_carve(wide_lds, maxnw);
+                        wide_zero_counts(Wd, lane);
+                        if (C.xw) { if (lane < 16) xw_carve(C.xw, 64).cnt[lane] = 0; xw_sync(); }
+                        bool any_xw = false;
+                        for (u32 i = 0; i < ndefer && i < 128u; ++i) {
+                            const int x = (int)mw_uni(((const unsigned short *)(L.defer + 1))[i]);
+                            const u32 w0 = CL.chg[4 * x], kk = CL.chg[4 * x + 2], off = CL.chg[4 * x + 3];
+                            const u32 a = CL.d[w0 & 0xFFu], b = CL.d[(w0 >> 8) & 0xFFu];
+                            const u32 o2 = (w0 >> 16) & 3u, n2 = (w0 >> 20) & 3u;
+                            const bool agb = a > b;
+                            const u32 dirs = (agb ? (o2 & 1u) : (o2 >> 1)) | ((agb ? (o2 >> 1) : (o2 & 1u)) << 1) | ((agb ? (n2 & 1u) : (n2 >> 1)) << 2) | ((agb ? (n2 >> 1) : (n2 & 1u)) << 3);
+                            if ((int)kk + 2 > 64 * maxnw) any_xw = true;
+                            pst |= cq_wide_pair<true>(wide_lds, maxnw, C.xw, C.rows, C.stride32, C.nb, CL, x, agb ? a : b, agb ? b : a, off, (int)kk, dirs, MAXT);
+                        }
+                        if (ndefer > 128u) pst |= 32u;
+                        t_wide = ndefer;
+                        if (lane >= 2 && lane < 16 && lane - 1 <= MAXT) wide_d += Wd.cnt[lane - 1];
+                        if (any_xw && lane >= 2 && lane < 16 && lane - 1 <= MAXT) wide_d += xw_count(C.xw, lane - 1);
+                        wave_sync();
                     }
                 }
             }
-            wave_sync();
         }
-        {   // tallies (OT_*): lanes 0..9 add, lanes 10..11 OR
-            const u32 acc_inc = commit | ((nonempty ^ 1u) & in_bounds);        // an empty transition is accepted iff the state is inside the bounds (:186-187)
-            const u64 im = (u64)(kind | (acc_inc << OT_ACCEPTED) | (t_big << OT_BIG));
-            u32 inc = lane_in(im) ? 1u : 0u;
-            inc = lane_in(1ull << OT_WIDE) ? t_wide : inc;
-            inc = lane_in(1ull << OT_SUMK) ? t_sumk : inc;
-            inc = lane_in(1ull << OT_CHANGES) ? t_changes : inc;
-            const u32 orv = lane_in(1ull << OT_NZ) ? nzm : pst;
-            const u32 taddr = mw_lds_addr(tly) + (u32)lane * 4u;
-            asm volatile("s_mov_b64 exec, 0x3ff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0xc00\n\tds_or_b32 %0, %2\n\ts_mov_b64 exec, -1"
-                         :: "v"(taddr), "v"(inc), "v"(orv) : "memory");
+
+        if (wv == 0) {
+            // ---- sampled += 1; Bounds::check; accept or drop (src/lib.rs:185-191)
+            const u32 eoff = (u32)min(lane, 8) * 32u;
+            const uint4 dyn = *(const uint4 *)((const char *)ent + eoff);
+            const uint4 stat = *(const uint4 *)((const char *)ent + eoff + 16u);
+            const u64 bmin = (u64)stat.x | ((u64)stat.y << 32), bmax = (u64)stat.z | ((u64)stat.w << 32);
+            const u64 cnt = (u64)dyn.x | ((u64)dyn.y << 32);
+            const u32 in_bounds = rdlane(dyn.z, 0);
+            const u64 ncnt = cnt + (u64)((long long)myd + wide_d);
+            const u64 outside = ballot(ncnt < bmin) | ballot(ncnt > bmax);
+            const u32 commit = outside == 0ull ? nonempty : 0u;
+            if (nonempty && (ballot((long long)ncnt < 0) & 0xFFull)) pst |= 8u;   // reference assert, src/lib.rs:65 (counts stay far below 2^63)
+            // flag_count grows to post's length when the transition is applied, accepted or not, and never shrinks (src/lib.rs:72-74, 89-91)
+            const u32 nzm = nonempty ? (u32)(ballot(ncnt != 0ull) & 0xFFull) : 0u;
+            if (commit) {
+                if (lane < 8) ent[lane * 4] = ncnt;
+                if (lane == 0 && !in_bounds) ent[1] = 1ull;
+                if (move >= 2) {
+                    cq_commit(C.rows, C.stride32, CL, npairs, lane);
+                    pst |= clique_update_slots(C.dbl, slot_of, CL, npairs, lane);
+                } else {
+                    const u32 flg = rdlane(sv, SR_FLAGS);
+                    const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
+                    const u32 bit_clr = 1u << ((flg >> 20) & 31u), bit_set = 1u << ((flg >> 25) & 31u);
+                    u32 nclr = w_clr & ~bit_clr, nset = w_set | bit_set;
+                    if (wid_clr == wid_set) { nclr |= bit_set; nset = nclr; }
+                    if (lane == 0) {
+                        C.rows[wid_clr] = nclr;
+                        C.rows[wid_set] = nset;
+                        if (flg & SRF_DMOVE) {   // the slot's pair stops being reciprocal, the single edge's pair becomes so
+                            const u32 slot = rdlane(sv, SR_DSLOT), was = rdlane(sv, SR_ID1), now = rdlane(sv, SR_ID2);
+                            slot_of[was] = FCM_NOSLOT;
+                            slot_of[now] = slot;
+                            C.dbl[slot] = now;
+                        }
+                    }
+                }
+                wave_sync();
+            }
+            if (move >= 2 && dix && nonempty) {   // the lookup table back to zero
+                const u32 nd = tly[CS_ND];
+                if (lane < (int)nd) L.dix[CL.d[lane]] = 0;
+                wave_sync();
+            }
+            {   // tallies (OT_*): lanes 0..9 add, lanes 10..11 OR
+                const u32 acc_inc = commit | ((nonempty ^ 1u) & in_bounds);        // an empty transition is accepted iff the state is inside the bounds (:186-187)
+                const u64 im = (u64)(kind | (acc_inc << OT_ACCEPTED) | (t_big << OT_BIG));
+                u32 inc = lane_in(im) ? 1u : 0u;
+                inc = lane_in(1ull << OT_WIDE) ? t_wide : inc;
+                inc = lane_in(1ull << OT_SUMK) ? t_sumk : inc;
+                inc = lane_in(1ull << OT_CHANGES) ? t_changes : inc;
+                const u32 orv = lane_in(1ull << OT_NZ) ? nzm : pst;
+                const u32 taddr = mw_lds_addr(tly) + (u32)lane * 4u;
+                asm volatile("s_mov_b64 exec, 0x3ff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0xc00\n\tds_or_b32 %0, %2\n\ts_mov_b64 exec, -1"
+                             :: "v"(taddr), "v"(inc), "v"(orv) : "memory");
+            }
+            if (W > 1u && commit) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the commit's stores are in memory before the other waves go on
+        }
+        if (W > 1u) {                                                            // end of the proposal: the chain's state is the same for every wave
+            barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
     }
 
+    if (wv != 0) return;
     wave_sync();
     if (lane < p.ncounts) cnt_g[lane] = ent[lane * 4];
     const u32 tl = lane < 16 ? tly[lane] : 0u;
     const u32 nzall = rdlane(tl, OT_NZ);
     const u32 nlen = nzall ? (u32)(32 - __clz((int)nzall)) : 0u;
-    const u32 stw = rdlane(tl, OT_STATUS) | (guard.tripped ? 256u : 0u);
+    u32 stw = rdlane(tl, OT_STATUS);
     if (lane == 0) {
         st_g[0] = sampled0 + N; st_g[1] += rdlane(tl, OT_ACCEPTED); st_g[2] += rdlane(tl, OT_EMPTY); st_g[3] += rdlane(tl, OT_FLIP);
         st_g[4] += rdlane(tl, OT_DMOVE); st_g[5] += rdlane(tl, OT_SUMK); if (nlen > st_g[6]) st_g[6] = nlen; st_g[7] |= stw;
@@ -582,10 +588,11 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
     }
 }
 
-template <int MAXT, bool ROWS128, bool XW>
-__global__ __launch_bounds__(WAVE, 4) void fcm_step_cq_kernel(const FcmStepParams p)
+// (W is a launch parameter: the block is W x 64 threads.  4 waves per SIMD: at most 128 VGPRs.)
+template <int MAXT>
+__global__ __launch_bounds__(CQ_MAXW * WAVE, 4) void fcm_step_cq_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];
     if (blockIdx.x >= p.nchains) return;
-    cq_wave<MAXT, ROWS128, XW>(p, smem);
+    cq_wave<MAXT>(p, smem);
 }

@@ -3,6 +3,9 @@
 //   EXACT=1: the tracked depth tmax (= count entries - 2) IS FCM_MAXT, a compile-time constant: the
 //            clique walk has exactly that many levels and no depth checks (tags x2_0 .. x6_1);
 //   EXACT=0: tmax <= FCM_MAXT at run time (tags 6_0, 14_0, 6_1, 14_1).
+#if defined(FCM_PC) && FCM_PC >= 3
+#define MW_TBL_N 20u   // (the clique-move kernel: a shorter draw table, so that its workgroup stays within 10 KiB of LDS -- 16 per CU)
+#endif
 #include "fcm_kernels_common.hpp"
 #include "fcm_step_mw.hpp"
 #include "fcm_step_cq.hpp"
@@ -22,12 +25,13 @@
 #endif
 
 #if defined(FCM_PC) && FCM_PC >= 3
-// tags c2_1 .. c6_1 (rows of one cache line, FCM_PC=3) and d2_1 .. d6_1 (longer rows, FCM_PC=4): the step kernel for move
-// mixes with clique moves (fcm_step_cq.hpp): pairs of a move on the pre-move bitmap, one commit on accept
+// tags c2_1 .. c6_1: the cooperative step kernel for move mixes with clique moves (fcm_step_cq.hpp): W = p->mw_waves (or 1)
+// waves per chain, the pairs of a move on the pre-move bitmap, one commit on accept
 extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
 {
-    const size_t words = fcm_cq_lds_words(p->maxnw < 2 ? 2 : p->maxnw, p->chg_cap);
-    fcm_step_cq_kernel<FCM_MAXT, FCM_PC == 3, true><<<dim3(p->nchains), dim3(WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
+    const unsigned W = p->mw_waves >= 2 ? p->mw_waves : 1u;
+    const size_t words = fcm_cq_lds_words(p->maxnw < 2 ? 2 : p->maxnw, p->chg_cap, W);
+    fcm_step_cq_kernel<FCM_MAXT><<<dim3(p->nchains), dim3(W * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
     return (int)hipGetLastError();
 }
 #elif defined(FCM_PC) && FCM_PC

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Debug aid: the clique-move kernel (fcm_step_cq) against the one-wave kernel (FCM_CQ=0), proposal by proposal."""
+"""Debug aid: the cooperative clique-move kernel (fcm_step_cq) with W waves per chain against the one-wave kernel (FCM_CQ=0),
+launch sizes 1, 7, 100.  usage: dbg_cq.py [W ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,27 +8,29 @@ import numpy as np
 import flag_complex_mcmc_amd as fcm
 from flag_complex_mcmc_amd import graphs
 
-n, pr, gseed, seed = 40, 0.35, 1, 4
-weights = tuple(float(x) for x in (sys.argv[1:5] or (0, 0, 1, 0)))
-e = graphs.random_with_p(n, pr, seed=gseed)
-g = fcm.Graph.from_edges(n, e)
-fc = g.flagser_count()
-b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.2))
-print("counts", fc)
-os.environ["FCM_CQ"] = "1"
-a = fcm.MCMCSampler(g, b, n_chains=3, seed=seed, move_weights=weights)
-os.environ["FCM_CQ"] = "0"
-o = fcm.MCMCSampler(g, b, n_chains=3, seed=seed, move_weights=weights)
-for step in range(300):
-    a.step(1); o.step(1)
-    sa, so = a.stats(), o.stats()
-    ca, co = a.flag_counts(), o.flag_counts()
-    for c in range(3):
-        if (ca[c] != co[c]).any() or any(sa[k][c] != so[k][c] for k in ("accepted", "n_changes", "sum_k", "status")):
-            print("step", step, "chain", c)
-            print(" cq :", ca[c].tolist(), {k: int(sa[k][c]) for k in sa})
-            print(" old:", co[c].tolist(), {k: int(so[k][c]) for k in so})
-            ea, eo = {tuple(x) for x in a.edges(c).tolist()}, {tuple(x) for x in o.edges(c).tolist()}
-            print(" edges only cq:", sorted(ea - eo), "only old:", sorted(eo - ea))
-            sys.exit(1)
-print("identical for 300 proposals")
+ok = True
+for (n, pr, gseed, rel) in ((40, 0.35, 1, 0.2), (300, 0.12, 3, 0.02), (1000, 0.10, 0, 0.01)):
+    e = graphs.random_with_p(n, pr, seed=gseed)
+    g = fcm.Graph.from_edges(n, e)
+    fc = g.flagser_count()
+    if len(fc) > 8:
+        continue
+    b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, rel))
+    for weights in ((0.1, 0.1, 0.6, 0.2), (0, 0, 1, 0), (0, 0, 0, 1)):
+        os.environ["FCM_CQ"] = "0"
+        o = fcm.MCMCSampler(g, b, n_chains=6, seed=4, move_weights=weights)
+        for nstep in (1, 7, 100):
+            o.step(nstep)
+        os.environ["FCM_CQ"] = "1"
+        for W in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+            os.environ["FCM_CQW"] = str(W)
+            a = fcm.MCMCSampler(g, b, n_chains=6, seed=4, move_weights=weights)
+            assert a.info["waves_per_chain"] == W, a.info
+            for nstep in (1, 7, 100):
+                a.step(nstep)
+            sa, so = a.stats(), o.stats()
+            same = (a.flag_counts() == o.flag_counts()).all() and all((sa[k] == so[k]).all() for k in ("accepted", "n_changes", "sum_k", "status", "count_len", "n_cperm", "n_cswap", "n_flip", "n_dmove"))
+            same = same and all((a.edges(c) == o.edges(c)).all() and (a.double_slots(c) == o.double_slots(c)).all() for c in range(6))
+            print("n=%d weights=%s W=%d: %s" % (n, weights, W, "identical" if same else "DIFFERENT"), flush=True)
+            ok = ok and same
+sys.exit(0 if ok else 1)
