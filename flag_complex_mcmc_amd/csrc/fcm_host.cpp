@@ -1053,8 +1053,12 @@ try {
         p.mw_waves = W >= 2 ? W : 0u;
         // Move mixes with clique moves: the kernel that evaluates a move's pairs on the pre-move bitmap (fcm_step_cq.hpp), for
         // up to 8 count entries like the multi-wave kernel; otherwise, or with FCM_CQ=0, the one-wave kernel's clique path.
+        // Measured on configs[2]'s graph (default mix, profiles/r03_default_mix_*): 2048 chains 6.9e7 vs 5.5e7 proposals/s, 1024
+        // chains 4.8e7 vs 3.1e7, 256 chains 1.6e7 vs 0.8e7; with 4096 chains one wave per chain already fills the chip and the
+        // one-wave kernel, which needs no patches, is 4 % ahead (9.1e7 vs 8.7e7): it stays the choice there.  FCM_CQ=1 / 0 forces
+        // the one or the other.
         const char *cq = getenv("FCM_CQ");
-        s->use_cq = s->clique_moves && nc - 2 >= 2 && nc - 2 <= 6 && !(cq && atoi(cq) == 0);
+        s->use_cq = s->clique_moves && nc - 2 >= 2 && nc - 2 <= 6 && (cq ? atoi(cq) != 0 : C <= 2048);
         if (s->use_cq) {
             // W waves per chain share a move's pairs: as many as keep chains x W within the 4096 wave slots of 4 waves per SIMD
             // (128 VGPRs), at most 8 (a move changes about 6 pairs).  FCM_CQW=<1|2|4|8> overrides.

@@ -306,10 +306,12 @@ def test_local_sets_beyond_256_vertices(fcm, oracle, monkeypatch, t, p_page, mw)
 
 
 @pytest.mark.parametrize("t,p_page", [(300, 0.008), (700, 0.003)])
-def test_clique_moves_with_local_sets_beyond_256_vertices(fcm, oracle, t, p_page):
+def test_clique_moves_with_local_sets_beyond_256_vertices(fcm, oracle, monkeypatch, t, p_page):
     """The same hub pair under the reference's default move mix: {0, 1, page} are maximal cliques, so clique moves change
     the pair {0, 1} itself, whose local set of t vertices takes the HBM-workspace evaluator inside a clique move
-    (fcm_xwide.hpp: xw_edge).  Oracle twins, tolerance 0."""
+    (fcm_xwide.hpp: xw_edge).  Oracle twins, tolerance 0.  The one-wave kernel's variants 6_2 / 14_2 (FCM_CQ=0; the
+    cooperative kernel's deferred pairs: tests/test_clique_cooperative.py)."""
+    monkeypatch.setenv("FCM_CQ", "0")
     e = _book_graph(t, p_page, seed=t)
     s, tw = _run_parity(fcm, oracle, t, e, n_chains=3, steps=[64, 1500], seed=t + 2, weights=(0.0, 0.0, 0.75, 0.25), relaxation=0.3)   # clique moves only: every wide evaluation is a clique move's
     assert s.info["k_max"] == t - 2 and s.info["waves_per_chain"] == 1
@@ -702,7 +704,8 @@ def test_multi_wave_kernel_is_selected_and_switchable(fcm, monkeypatch):
     assert fcm.MCMCSampler(g, b, n_chains=1024, seed=1).info["waves_per_chain"] == 8
     assert fcm.MCMCSampler(g, b, n_chains=3000, seed=1).info["waves_per_chain"] == 2      # 3000 x 4 would not all be resident
     assert fcm.MCMCSampler(g, b, n_chains=4096, seed=1).info["waves_per_chain"] == 2      # chains x W = the chip's 8192 wave slots
-    assert fcm.MCMCSampler(g, b, n_chains=2, seed=1, move_weights=fcm.MOVE_DISTRIBUTION).info["waves_per_chain"] == 1  # clique moves
+    assert fcm.MCMCSampler(g, b, n_chains=2, seed=1, move_weights=fcm.MOVE_DISTRIBUTION).info["waves_per_chain"] == 8     # clique moves: the cooperative kernel, W by chain count
+    assert fcm.MCMCSampler(g, b, n_chains=4096, seed=1, move_weights=fcm.MOVE_DISTRIBUTION).info["waves_per_chain"] == 1  # ... and the one-wave kernel beyond 2048 chains
     monkeypatch.setenv("FCM_MW", "1")
     assert fcm.MCMCSampler(g, b, n_chains=2, seed=1).info["waves_per_chain"] == 1
     monkeypatch.setenv("FCM_MW", "4")
