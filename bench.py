@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 # BASELINE.json configs[i] -> (description, per-GPU chains, default proposals per chain per step)
 CONFIGS = {
     1: ("configs[1]: C. elegans stand-in (tests/golden/bug_calc_relax_de.flag, n=279), 1024 chains", 1024, 65536),
-    2: ("configs[2]: Erdos-Renyi digraph n=1000 p=0.10 seed 0, 4096 chains per GPU", 4096, 16384),
+    2: ("configs[2]: Erdos-Renyi digraph n=1000 p=0.10 seed 0, 4096 chains per GPU", 4096, 65536),
     3: ("configs[3]: Erdos-Renyi digraph n=4000 p=0.05 seed 0, 1024 chains per GPU (8192 over 8)", 1024, 16384),
     4: ("configs[4]: n=30000, 1M directed edge draws seed 0, 256 chains per GPU (2048 over 8)", 256, 32768),
 }
@@ -84,18 +84,34 @@ def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
             "single_thread_proposals_per_s": 1.0 / per_prop}
 
 
-def load_traffic(config, n_chains, proposals, moves="simple"):
+def lib_sha16(path):
+    """First 16 hex digits of the SHA-256 of the library file: what ties a profile to the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def load_traffic(config, n_chains, proposals, moves, this_lib):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC summary of this same command
     (profiles/pmc_summary.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE
-    passes), or (None, None).  A replay of a profiled run, not a measurement of this one: the source says so."""
+    passes), or (None, why).  A replay of a profiled run, not a measurement of this one: the source says so.  The
+    counters scale with the proposals per launch (every launch runs the same loop), so a record taken at another launch
+    length is scaled; a record taken on ANOTHER BUILD of the library is not used at all."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         recs = json.load(open(path))
-        for rec in (recs if isinstance(recs, list) else [recs]):
-            if rec.get("config", 2) == config and rec.get("n_chains") == n_chains and rec.get("proposals") == proposals and rec.get("moves", "simple") == moves:
-                return rec.get("hbm_bytes_per_launch"), "replayed from profiles/pmc_summary.json (%s): rocprofv3 --pmc passes of this command, not this run" % rec.get("tag", "?")
     except Exception:
-        pass
+        return None, None
+    for rec in (recs if isinstance(recs, list) else [recs]):
+        if rec.get("config", 2) == config and rec.get("n_chains") == n_chains and rec.get("moves", "simple") == moves:
+            if rec.get("lib_sha16") != this_lib:
+                return None, "STALE: profiled build %s != this build %s (profiles/pmc_summary.json, %s)" % (rec.get("lib_sha16"), this_lib, rec.get("tag", "?"))
+            scale = float(proposals) / float(rec.get("proposals") or proposals)
+            return rec.get("hbm_bytes_per_launch") * scale, ("replayed from profiles/pmc_summary.json (%s, build %s%s): rocprofv3 --pmc passes of this command, not this run"
+                                                             % (rec.get("tag", "?"), this_lib, "" if scale == 1.0 else ", scaled x%g from %d proposals per launch" % (scale, rec.get("proposals"))))
     return None, None
 
 
@@ -283,7 +299,8 @@ def main():
         long_rows = n > 1024
         abytes = needed_bytes(d, n, mean_k) / args.steps if long_rows else survey_bytes
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals, args.moves)
+        this_lib = lib_sha16(fcm.LIB_PATH)
+        traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals, args.moves, this_lib)
         out = {
             "metric": METRIC, "value": total_prop / elapsed, "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -294,6 +311,7 @@ def main():
                        "baseline_config": args.config, "n": n, "chains_per_gpu": args.chains, "proposals_per_step": args.proposals,
                        "edges": int(len(edges)), "initial_flag_count": flag_count, "parallelism": "chains sharded, %d rank(s)" % world},
             "per_gpu_value": total_prop / elapsed / world,
+            "lib_sha16": this_lib,
             "kernel_ms_per_launch": kernel_ms,
             "accept_ratio": float(d["accepted"]) / float(d["sampled"]),
             "empty_fraction": float(d["n_empty"]) / float(d["sampled"]),

@@ -35,14 +35,14 @@ def test_every_W_against_oracle_twins_on_dense_small_graphs(fcm, oracle, monkeyp
     monkeypatch.setenv("FCM_CQW", w)
     want = int(w) if cq == "1" else 1
     changes = rejected = 0
-    for n, pr, gseed in ((40, 0.35, 1), (24, 0.5, 2), (60, 0.2, 5)):
+    for n, pr, gseed in ((40, 0.35, 1), (60, 0.2, 5)):
         e = fcm.graphs.random_with_p(n, pr, seed=gseed)
         for weights in ((0.0, 0.0, 1.0, 0.0), (0.0, 0.0, 0.0, 1.0), (0.1, 0.1, 0.6, 0.2)):
-            s = _twins(fcm, oracle, n, e, weights, 3, [1, 1, 7, 61, 200], 4, 0.2, want)
+            s = _twins(fcm, oracle, n, e, weights, 2, [1, 7, 120], 4, 0.2, want)
             st = s.stats()
             changes += int(st["n_changes"].sum())
             rejected += int((st["sampled"] - st["accepted"]).sum())
-    assert changes > 5000 and rejected > 50      # (rejected moves: nothing was written, nothing to put back)
+    assert changes > 2000 and rejected > 20      # (rejected moves: nothing was written, nothing to put back)
 
 
 @pytest.mark.parametrize("cq,w", [("1", "2"), ("1", "8")])
