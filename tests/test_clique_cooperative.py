@@ -57,6 +57,18 @@ def test_every_W_on_the_bench_graph_default_mix(fcm, oracle, monkeypatch, cq, w)
     assert (s.stats()["n_cperm"] > 250).all() and (s.stats()["n_cswap"] > 60).all()
 
 
+@pytest.mark.parametrize("w", ["1", "4"])
+def test_graphs_of_more_than_1024_vertices(fcm, oracle, monkeypatch, w):
+    """Rows longer than a cache line: no vertex -> d-index table in LDS (it covers 1024 vertices), the patches find their
+    positions by comparing; the simple moves' exact run takes the looped build."""
+    monkeypatch.setenv("FCM_CQ", "1")
+    monkeypatch.setenv("FCM_CQW", w)
+    n = 1100
+    e = fcm.graphs.random_with_p(n, 0.08, seed=2)
+    s = _twins(fcm, oracle, n, e, (0.1, 0.1, 0.6, 0.2), 2, [1, 64, 400], 11, 0.05, int(w))
+    assert s.info["row_words"] > 16 and (s.stats()["n_cswap"] > 30).all()
+
+
 def _book_graph(t, p_page, seed):
     """Two hubs joined to t page vertices (local set of t + 2 vertices for the hub pair), pages sparsely joined."""
     rng = np.random.default_rng(seed)
