@@ -46,7 +46,8 @@ class CSamplerInfo(C.Structure):
     _fields_ = [("n", C.c_uint32), ("row_words", C.c_uint32), ("n_undirected", C.c_uint64),
                 ("n_double", C.c_uint64), ("k_max", C.c_uint32), ("k_mean", C.c_double),
                 ("bytes_per_chain", C.c_uint64), ("bytes_static", C.c_uint64),
-                ("ncounts", C.c_int32), ("lossless", C.c_int32), ("n_chains", C.c_uint32), ("waves_per_chain", C.c_uint32)]
+                ("ncounts", C.c_int32), ("lossless", C.c_int32), ("n_chains", C.c_uint32), ("waves_per_chain", C.c_uint32),
+                ("sparse_state", C.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/fcm.h declares

@@ -214,6 +214,9 @@ int fcm_launch_step_m6_0(const FcmStepParams *, void *);
 int fcm_launch_step_n2_0(const FcmStepParams *, void *); int fcm_launch_step_n3_0(const FcmStepParams *, void *);
 int fcm_launch_step_n4_0(const FcmStepParams *, void *); int fcm_launch_step_n5_0(const FcmStepParams *, void *);
 int fcm_launch_step_n6_0(const FcmStepParams *, void *);
+int fcm_launch_step_s2_0(const FcmStepParams *, void *); int fcm_launch_step_s3_0(const FcmStepParams *, void *);
+int fcm_launch_step_s4_0(const FcmStepParams *, void *); int fcm_launch_step_s5_0(const FcmStepParams *, void *);
+int fcm_launch_step_s6_0(const FcmStepParams *, void *);
 int fcm_launch_step_c2_1(const FcmStepParams *, void *); int fcm_launch_step_c3_1(const FcmStepParams *, void *);
 int fcm_launch_step_c4_1(const FcmStepParams *, void *); int fcm_launch_step_c5_1(const FcmStepParams *, void *);
 int fcm_launch_step_c6_1(const FcmStepParams *, void *);
@@ -232,7 +235,9 @@ extern "C" int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, voi
                                                 fcm_launch_step_m5_0, fcm_launch_step_m6_0};   // rows of one cache line
         static const fcm_step_launcher nc[5] = {fcm_launch_step_n2_0, fcm_launch_step_n3_0, fcm_launch_step_n4_0,
                                                 fcm_launch_step_n5_0, fcm_launch_step_n6_0};   // longer rows
-        return (p->stride32 == 32u ? mc : nc)[tmax - 2](p, stream);
+        static const fcm_step_launcher sc[5] = {fcm_launch_step_s2_0, fcm_launch_step_s3_0, fcm_launch_step_s4_0,
+                                                fcm_launch_step_s5_0, fcm_launch_step_s6_0};   // sparse state
+        return (p->sparse ? sc : (p->stride32 == 32u ? mc : nc))[tmax - 2](p, stream);
     }
     if (clique == 3 && tmax >= 2 && tmax <= 6) {   // move mixes with clique moves: pairs on the pre-move bitmap, W waves per chain (fcm_step_cq.hpp)
         static const fcm_step_launcher cc[5] = {fcm_launch_step_c2_1, fcm_launch_step_c3_1, fcm_launch_step_c4_1, fcm_launch_step_c5_1, fcm_launch_step_c6_1};

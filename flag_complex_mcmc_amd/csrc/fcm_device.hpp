@@ -53,6 +53,9 @@ struct FcmStepParams {
     uint64_t *xw_ws;           // [n_chains][FCM_XW_WORDS] workspace of the evaluator for local sets of 257..1024 vertices (fcm_xwide.hpp); null if the graph has none
     uint64_t guard_limit;      // largest local count bound a walk may reach before it refuses (2^31 - 1; fcm_count_guard)
     uint32_t mw_waves;         // multi-wave kernel (fcm_step_mw.hpp): waves per chain, a power of two 2..16; 0 = one-wave kernel
+                               // (the cooperative clique-move kernel, fcm_step_cq.hpp: its waves per chain, 0 = 1)
+    uint32_t sparse;           // 1: `rows` holds, per chain, two bits per adjacent pair (rows_per_chain u32 words) instead of row bitmaps, and `nb`
+                               // the local pair ids behind every neighbour list (fcm_step_mw.hpp, mw_build_sparse); multi-wave kernel only
 };
 
 struct FcmCountParams {

@@ -695,6 +695,8 @@ struct fcm_sampler {
     // device buffers
     DevBuf d_etab, d_nb, d_rows, d_dbl, d_counts, d_stats, d_clq, d_clq_pairs, d_efirst, d_slot_of, d_dbg, d_xw;
     bool clique_moves = false;
+    bool sparse = false;               // per chain two bits per adjacent pair instead of row bitmaps (d_rows holds them; include/fcm.h, fcm_sampler_info)
+    uint32_t bits_stride = 0;          // ... u32 words per chain
     bool use_cq = false;               // move mixes with clique moves on the fcm_step_cq kernel (<= 8 count entries)
     // host copies of the static tables, fetched on the first use of the State API (apply/revert/edgeset_neighborhood)
     std::vector<FcmEdgeEntry> h_etab;
@@ -830,20 +832,57 @@ try {
                 etab[e].k = common(etab[e].big, etab[e].small, nullptr);
             }
         });
+        for (uint64_t e = 0; e < U; ++e) { kmax = std::max(kmax, etab[e].k); ksum += etab[e].k; }
+        // Sparse state: rows much longer than what a build reads of them -- more than 1024 vertices, local sets
+        // of at most 11 vertices, two common neighbours on average at most -- and the simple moves (the multi-wave kernel's
+        // domain; whether that kernel runs at all is settled below, with the count entries known).  FCM_SPARSE=0 / 1 overrides.
+        {
+            const bool simple = !(cfg->move_weights[2] > 0.0 || cfg->move_weights[3] > 0.0);
+            bool want = g->stride32 > 32 && U > 0 && (double)ksum <= 2.0 * (double)U;
+            if (const char *e = getenv("FCM_SPARSE")) want = atoi(e) != 0;
+            s->sparse = want && simple && U > 0 && kmax + 2 <= 11;
+        }
         uint64_t total = 0;
         for (uint64_t e = 0; e < U; ++e) {
             if (total > 0xFFFFFF00ull) return fail(FCM_ERR_UNSUPPORTED, "neighbourhood table exceeds 2^32 entries");
             etab[e].nb_off = (uint32_t)total;
             total += etab[e].k;
-            kmax = std::max(kmax, etab[e].k);
+            if (s->sparse && etab[e].k) {   // behind the list, from an even word on: two words per local pair
+                const uint64_t sl = (uint64_t)etab[e].k + 2;
+                total += (total & 1) + sl * (sl - 1);
+            }
             if (g->has(etab[e].big, etab[e].small) && g->has(etab[e].small, etab[e].big)) dbl0.push_back((uint32_t)e);
         }
         if (total > 0xFFFFFF00ull) return fail(FCM_ERR_UNSUPPORTED, "neighbourhood table exceeds 2^32 entries");
-        ksum = total;
-        nb.resize((size_t)total);
+        nb.assign((size_t)total, 0u);
+        auto pair_id = [&](uint32_t a, uint32_t b) -> uint32_t {   // etab index of {a, b}, 0xFFFFFFFF if not adjacent (ue is ascending (big, small))
+            const uint32_t big = std::max(a, b), small = std::min(a, b);
+            uint64_t lo = 0, hi = U;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) / 2;
+                if (s->ue[2 * mid] < big || (s->ue[2 * mid] == big && s->ue[2 * mid + 1] < small)) lo = mid + 1; else hi = mid;
+            }
+            return (lo < U && s->ue[2 * lo] == big && s->ue[2 * lo + 1] == small) ? (uint32_t)lo : 0xFFFFFFFFu;
+        };
         run_parallel([&](unsigned t) {   // pass 2: the lists (ascending, like the bitmap scan gives them)
-            for (uint64_t e = U * t / nthreads; e < U * (t + 1) / nthreads; ++e)
-                if (etab[e].k) common(etab[e].big, etab[e].small, &nb[etab[e].nb_off]);
+            for (uint64_t e = U * t / nthreads; e < U * (t + 1) / nthreads; ++e) {
+                const uint32_t k = etab[e].k;
+                if (!k) continue;
+                uint32_t *L = &nb[etab[e].nb_off];
+                common(etab[e].big, etab[e].small, L);
+                if (!s->sparse) continue;
+                // the local pairs (i < j, lexicographic; local indices: the list, then big, then small): pair id and i | j << 8 | swap << 16
+                // (swap: L[i] is the smaller vertex of that pair, i.e. its bit 2 id is L[j] -> L[i])
+                uint32_t *out = L + k + ((etab[e].nb_off + k) & 1u);
+                const uint32_t sl = k + 2;
+                auto vert = [&](uint32_t i) { return i < k ? L[i] : (i == k ? etab[e].big : etab[e].small); };
+                for (uint32_t i = 0; i < sl; ++i)
+                    for (uint32_t j = i + 1; j < sl; ++j) {
+                        const uint32_t a = vert(i), b = vert(j);
+                        *out++ = (i == k && j == k + 1) ? (uint32_t)e : pair_id(a, b);
+                        *out++ = i | (j << 8) | ((a < b ? 1u : 0u) << 16);
+                    }
+            }
         });
     }
     if (kmax + 2 > FCM_MAX_LOCAL)
@@ -872,7 +911,18 @@ try {
     s->maxt_variant = nc - 2;   // tracked depth; fcm_launch_step picks the kernel variant
 
     // --- device buffers -----------------------------------------------------
-    const uint64_t rows_per_chain = (uint64_t)g->n * g->stride32;
+    // Sparse state only under the multi-wave kernel: simple moves (checked above), 4..8 count entries, not switched off by FCM_MW.
+    // (Withdrawn here, the lists still carry the local pair ids behind them: nobody reads those then.)
+    {
+        bool mw_off = false;
+        if (const char *e = getenv("FCM_MW")) { const int v = atoi(e); mw_off = !(v == 2 || v == 4 || v == 8 || v == 16); }
+        if (!(nc - 2 >= 2 && nc - 2 <= 6) || mw_off) s->sparse = false;
+    }
+    if (s->sparse) {   // the chain's record: two bits per adjacent pair (bit 2e: big -> small, 2e + 1: small -> big), padded to whole 128-B lines
+        s->bits_stride = (uint32_t)((2 * U + 31) / 32);
+        s->bits_stride = (s->bits_stride + 31u) / 32u * 32u;
+    }
+    const uint64_t rows_per_chain = s->sparse ? (uint64_t)s->bits_stride : (uint64_t)g->n * g->stride32;
     const uint32_t dbl_stride = (uint32_t)((D + 31) / 32 * 32);
     const uint32_t C = cfg->n_chains;
     if ((rc = s->d_etab.alloc(std::max<size_t>(1, etab.size()) * sizeof(FcmEdgeEntry)))) return rc;
@@ -887,7 +937,16 @@ try {
     {
         DevBuf d_base;
         if ((rc = d_base.alloc(rows_per_chain * sizeof(uint32_t)))) return rc;
-        HIP_TRY(hipMemcpy(d_base.p, g->rows.data(), rows_per_chain * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (s->sparse) {
+            std::vector<uint32_t> bits((size_t)rows_per_chain, 0u);
+            for (uint64_t e = 0; e < U; ++e) {
+                if (g->has(etab[e].big, etab[e].small)) bits[(2 * e) >> 5] |= 1u << ((2 * e) & 31);
+                if (g->has(etab[e].small, etab[e].big)) bits[(2 * e + 1) >> 5] |= 1u << ((2 * e + 1) & 31);
+            }
+            HIP_TRY(hipMemcpy(d_base.p, bits.data(), rows_per_chain * sizeof(uint32_t), hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(hipMemcpy(d_base.p, g->rows.data(), rows_per_chain * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
         int lrc = fcm_launch_broadcast_rows(s->d_rows.as<uint32_t>(), d_base.as<uint32_t>(), rows_per_chain, C, nullptr);
         if (lrc) return fail(FCM_ERR_HIP, "broadcast launch failed: %s", hipGetErrorString((hipError_t)lrc));
         HIP_TRY(hipDeviceSynchronize());
@@ -1014,6 +1073,7 @@ try {
     p.ncounts = nc;
     p.maxnw = s->maxnw_variant;
     p.xw_ws = need_xw ? s->d_xw.as<uint64_t>() : nullptr;
+    p.sparse = s->sparse ? 1u : 0u;
     p.guard_limit = 0x7FFFFFFFull;
     if (const char *e = getenv("FCM_TEST_GUARD_LIMIT")) p.guard_limit = strtoull(e, nullptr, 10);   // test hook (tests/test_gpu_parity.py)
 
@@ -1026,6 +1086,7 @@ try {
     I.n_double = D;
     I.k_max = kmax;
     I.k_mean = U ? (double)ksum / (double)U : 0.0;
+    I.sparse_state = s->sparse ? 1u : 0u;
     I.bytes_per_chain = rows_per_chain * 4 + (uint64_t)dbl_stride * 4 + FCM_MAX_COUNTS * 8 + FCM_NSTATS * 8 + (s->clique_moves ? U * 4 : 0) + (need_xw ? FCM_XW_WORDS_HOST * 8 : 0);
     I.bytes_static = etab.size() * sizeof(FcmEdgeEntry) + nb.size() * 4 + ct.flat.size() * 4 + clq_pairs_bytes;
     I.ncounts = nc;
@@ -1178,11 +1239,31 @@ try {
     return FCM_OK;
 } FCM_CATCH
 
+// sparse state: the chain's record (bits_stride words)
+static int fetch_bits(fcm_sampler *s, uint32_t chain, std::vector<uint32_t> &bits)
+{
+    bits.resize((size_t)s->bits_stride);
+    HIP_TRY(hipMemcpy(bits.data(), s->d_rows.as<uint32_t>() + (size_t)chain * s->bits_stride, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return FCM_OK;
+}
+
 static int fetch_rows(fcm_sampler *s, uint32_t chain, std::vector<uint32_t> &rows)
 {
     if (chain >= s->params.nchains) return fail(FCM_ERR_INVALID, "chain %u out of range", chain);
     int rc = fcm_sampler_sync(s);
     if (rc) return rc;
+    if (s->sparse) {   // expand the chain's two bits per pair into row bitmaps
+        std::vector<uint32_t> bits;
+        if ((rc = fetch_bits(s, chain, bits))) return rc;
+        rows.assign((size_t)s->n * s->stride32, 0u);
+        const uint64_t U = s->ue.size() / 2;
+        for (uint64_t e = 0; e < U; ++e) {
+            const uint32_t a = s->ue[2 * e], b = s->ue[2 * e + 1];
+            if ((bits[(2 * e) >> 5] >> ((2 * e) & 31)) & 1u) rows[(size_t)a * s->stride32 + (b >> 5)] |= 1u << (b & 31);
+            if ((bits[(2 * e + 1) >> 5] >> ((2 * e + 1) & 31)) & 1u) rows[(size_t)b * s->stride32 + (a >> 5)] |= 1u << (a & 31);
+        }
+        return FCM_OK;
+    }
     rows.resize((size_t)s->params.rows_per_chain);
     HIP_TRY(hipMemcpy(rows.data(), s->d_rows.as<uint32_t>() + (size_t)chain * s->params.rows_per_chain,
                       rows.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1220,6 +1301,15 @@ try {
     if (nbytes) *nbytes = need;
     if (!out) return FCM_OK;
     if (cap < need) return fail(FCM_ERR_INVALID, "edgebits buffer too small: need %llu", (unsigned long long)need);
+    if (s->sparse) {   // the record IS the chain's state
+        if (chain >= s->params.nchains) return fail(FCM_ERR_INVALID, "chain %u out of range", chain);
+        int rcs = fcm_sampler_sync(s);
+        if (rcs) return rcs;
+        std::vector<uint32_t> bits;
+        if ((rcs = fetch_bits(s, chain, bits))) return rcs;
+        memcpy(out, bits.data(), (size_t)need);
+        return FCM_OK;
+    }
     std::vector<uint32_t> rows;
     int rc = fetch_rows(s, chain, rows);
     if (rc) return rc;
@@ -1346,6 +1436,14 @@ try {
     return FCM_OK;
 } FCM_CATCH
 
+static inline bool sub_has(const std::vector<uint32_t> &sub, uint32_t nlw, uint32_t i, uint32_t j) { return (sub[(size_t)i * nlw + (j >> 5)] >> (j & 31)) & 1u; }
+static inline void sub_set(std::vector<uint32_t> &sub, uint32_t nlw, uint32_t i, uint32_t j, bool present)
+{
+    uint32_t &w = sub[(size_t)i * nlw + (j >> 5)];
+    const uint32_t b = 1u << (j & 31);
+    w = present ? (w | b) : (w & ~b);
+}
+
 // induced adjacency of `list` in the chain's current graph: sub[i * nlw + w], bit j = list[i] -> list[j]
 static int gather_sub(fcm_sampler *s, uint32_t chain, const std::vector<uint32_t> &list, std::vector<uint32_t> &sub, uint32_t &nlw)
 {
@@ -1354,6 +1452,20 @@ static int gather_sub(fcm_sampler *s, uint32_t chain, const std::vector<uint32_t
     sub.assign((size_t)nl * nlw, 0u);
     if (nl == 0) return FCM_OK;
     int rc;
+    if (s->sparse) {   // read off the chain's record on the host
+        std::vector<uint32_t> bits;
+        if ((rc = fetch_bits(s, chain, bits))) return rc;
+        for (uint32_t i = 0; i < nl; ++i)
+            for (uint32_t j = 0; j < i; ++j) {
+                const int64_t e = pair_index(s, list[i], list[j]);
+                if (e < 0) continue;
+                const bool ibig = list[i] > list[j];
+                const bool bs = (bits[(2 * e) >> 5] >> ((2 * e) & 31)) & 1u, sb = (bits[(2 * e + 1) >> 5] >> ((2 * e + 1) & 31)) & 1u;
+                sub_set(sub, nlw, i, j, ibig ? bs : sb);
+                sub_set(sub, nlw, j, i, ibig ? sb : bs);
+            }
+        return FCM_OK;
+    }
     if (s->tr_list_cap < nl) { DevBuf nb_; if ((rc = nb_.alloc((size_t)nl * 4))) return rc; std::swap(s->d_tr_list.p, nb_.p); s->tr_list_cap = nl; }
     if (s->tr_out_cap < sub.size()) { DevBuf nb_; if ((rc = nb_.alloc(sub.size() * 4))) return rc; std::swap(s->d_tr_out.p, nb_.p); s->tr_out_cap = sub.size(); }
     HIP_TRY(hipMemcpyAsync(s->d_tr_list.p, list.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s->stream));
@@ -1379,13 +1491,6 @@ static int count_sub(const fcm_sampler *s, const std::vector<uint32_t> &sub, uin
     return device_count(rows.data(), nl, st, edges, s->device, counts, len);
 }
 
-static inline bool sub_has(const std::vector<uint32_t> &sub, uint32_t nlw, uint32_t i, uint32_t j) { return (sub[(size_t)i * nlw + (j >> 5)] >> (j & 31)) & 1u; }
-static inline void sub_set(std::vector<uint32_t> &sub, uint32_t nlw, uint32_t i, uint32_t j, bool present)
-{
-    uint32_t &w = sub[(size_t)i * nlw + (j >> 5)];
-    const uint32_t b = 1u << (j & 31);
-    w = present ? (w | b) : (w & ~b);
-}
 
 // The chain's reciprocal-pair slot list after set_edge calls: the pairs (ascending id) that stopped being reciprocal
 // hand their slots to the pairs that became reciprocal, in order (the rule of the clique moves).  The
@@ -1440,6 +1545,18 @@ static int commit_slots(fcm_sampler *s, uint32_t chain, const SlotPlan &plan)
 static int set_edges_on_device(fcm_sampler *s, uint32_t chain, const fcm_node *edges, const int32_t *add, uint32_t n, bool invert)
 {
     if (n == 0) return FCM_OK;
+    if (s->sparse) {
+        std::vector<uint32_t> bits;
+        int rcs = fetch_bits(s, chain, bits);
+        if (rcs) return rcs;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t a = edges[2 * i], b = edges[2 * i + 1];
+            const uint64_t bit = 2 * (uint64_t)pair_index(s, a, b) + (a > b ? 0 : 1);
+            if ((add[i] != 0) != invert) bits[bit >> 5] |= 1u << (bit & 31); else bits[bit >> 5] &= ~(1u << (bit & 31));
+        }
+        HIP_TRY(hipMemcpy(s->d_rows.as<uint32_t>() + (size_t)chain * s->bits_stride, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return FCM_OK;
+    }
     std::vector<uint32_t> chg((size_t)n * 3);
     for (uint32_t i = 0; i < n; ++i) { chg[3 * i] = edges[2 * i]; chg[3 * i + 1] = edges[2 * i + 1]; chg[3 * i + 2] = ((add[i] != 0) != invert) ? 1u : 0u; }
     int rc;
@@ -1544,9 +1661,15 @@ try {
     const uint32_t big = s->ue[2 * (size_t)r], small = s->ue[2 * (size_t)r + 1];
     const uint32_t *rows = s->d_rows.as<uint32_t>() + (size_t)chain * s->params.rows_per_chain;
     uint32_t wbs = 0, wsb = 0;
-    HIP_TRY(hipMemcpy(&wbs, rows + (size_t)big * s->stride32 + (small >> 5), 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&wsb, rows + (size_t)small * s->stride32 + (big >> 5), 4, hipMemcpyDeviceToHost));
-    const bool bs = (wbs >> (small & 31)) & 1u, sb = (wsb >> (big & 31)) & 1u;
+    bool bs, sb;
+    if (s->sparse) {
+        HIP_TRY(hipMemcpy(&wbs, rows + ((2 * r) >> 5), 4, hipMemcpyDeviceToHost));
+        bs = (wbs >> ((2 * r) & 31)) & 1u; sb = (wbs >> ((2 * r + 1) & 31)) & 1u;
+    } else {
+        HIP_TRY(hipMemcpy(&wbs, rows + (size_t)big * s->stride32 + (small >> 5), 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&wsb, rows + (size_t)small * s->stride32 + (big >> 5), 4, hipMemcpyDeviceToHost));
+        bs = (wbs >> (small & 31)) & 1u; sb = (wsb >> (big & 31)) & 1u;
+    }
     if (bs == sb) {
         if (!bs) return fail(FCM_ERR_INTERNAL, "chain %u: pair (%u,%u) is adjacent in the table and absent from the bitmap", chain, big, small);
         return FCM_OK;                                                          // reciprocal: empty transition (:297-298)
@@ -1674,8 +1797,14 @@ try {
     for (uint32_t c = 0; c < h.n_chains; ++c) {
         if (!rd(f, bits.data(), bits.size()) || !rd(f, dbl.data(), dbl.size())) return fail(FCM_ERR_IO, "%s: truncated", path);
         apply_bits(*g);
-        HIP_TRY(hipMemcpy(s->d_rows.as<uint32_t>() + (size_t)c * s->params.rows_per_chain, g->rows.data(),
-                          (size_t)s->params.rows_per_chain * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (s->sparse) {
+            std::vector<uint32_t> w((size_t)s->bits_stride, 0u);
+            memcpy(w.data(), bits.data(), bits.size());
+            HIP_TRY(hipMemcpy(s->d_rows.as<uint32_t>() + (size_t)c * s->bits_stride, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(hipMemcpy(s->d_rows.as<uint32_t>() + (size_t)c * s->params.rows_per_chain, g->rows.data(),
+                              (size_t)s->params.rows_per_chain * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
         uint64_t nd = 0;
         for (uint64_t e = 0; e < U; ++e) nd += g->has(ue[2 * e], ue[2 * e + 1]) && g->has(ue[2 * e + 1], ue[2 * e]);
         if (nd != D) return fail(FCM_ERR_IO, "%s: chain %u has %llu reciprocal pairs, header says %llu", path, c,

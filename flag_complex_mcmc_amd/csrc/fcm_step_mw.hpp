@@ -145,6 +145,39 @@ __device__ __forceinline__ u64 mw_build(const rsrc_t rr, u32 stride32, u32 Lv, i
     else return build_local_loop16(rr, stride32, Lv, s, lane);
 }
 
+// ---- sparse state (graphs whose rows are long and whose local sets are tiny: BASELINE configs[4], n = 30000, k ~ 0.1) -----------
+// Per chain, instead of row bitmaps: two bits per adjacent pair e of pr(G) -- bit 2e = big -> small, bit 2e+1 = small -> big,
+// the reference's edgebits layout (src/io.rs:152-159) -- 250 KB per chain at n = 30000 instead of 115 MB.  The static side
+// names, behind a pair's neighbour list in `nb`, the pairs among its local set: for every local pair (i < j, lexicographic;
+// local indices as in the list: K ascending, then big, then small; the pair itself last) two words: its pair id (MW_NONE: not
+// adjacent) and i | j << 8 | (L[i] is that pair's `big` ? 0 : 1) << 16.  A build is then one coalesced read of those entries
+// (none at all for k = 0, nine proposals in ten on configs[4]) and one dword gather from the chain's bits.  Local sets of up to
+// 11 vertices (55 local pairs, one per lane); the host selects the layout only for such graphs.
+#define MW_SPARSE_MAX_S 11
+__device__ __forceinline__ u64 mw_build_sparse(const rsrc_t rbits, const u32 *nb, u32 off, int k, u32 pid, int lane)
+{
+    const int s = k + 2, T = s * (s - 1) / 2;
+    u32 id = MW_NONE, ij = 0u;
+    if (k == 0) {                       // the pair alone: nothing to look up
+        id = pid; ij = 0u | (1u << 8);
+    } else if (lane < T) {
+        const u32 base = (off + (u32)k + 1u) & ~1u;   // (the entries start at an even word: 8-byte reads)
+        const uint2 e = *(const uint2 *)(nb + base + 2u * (u32)lane);
+        id = e.x; ij = e.y;
+    }
+    const bool have = lane < T && id != MW_NONE;
+    const u32 word = have ? (u32)__builtin_amdgcn_raw_buffer_load_b32(rbits, (id >> 4) * 4u, 0, 0) : 0u;   // bits 2 id, 2 id + 1 of the chain's record
+    const u32 two = (word >> ((id & 15u) * 2u)) & 3u;
+    const u32 f = (ij >> 16) & 1u ? (((two >> 1) & 1u) | ((two & 1u) << 1)) : two;   // bit 0: L[i] -> L[j], bit 1: L[j] -> L[i]
+    u64 h = 0ull;
+    for (int t = 0; t < T; ++t) {       // (wave-uniform; one trip for k = 0)
+        const u32 e = rdlane(ij, t), ft = rdlane(f, t);
+        const u32 i = e & 0xFFu, j = (e >> 8) & 0xFFu;
+        h |= (lane == (int)j ? (u64)(ft & 1u) << i : 0ull) | (lane == (int)i ? (u64)(ft >> 1) << j : 0ull);
+    }
+    return h;
+}
+
 // The wave's tallies, u32 words in LDS (added to the chain's stats row at the end): counters (the first four are the low
 // bits of the staged flags word), then one flag per count entry -- was it ever non-zero after a transition (flag_count
 // never shrinks in length, src/lib.rs:72-74) -- and the OR of the proposals' status words.  In LDS rather than in a
@@ -241,7 +274,7 @@ __device__ __forceinline__ void mw_stage(u32 *stage, const MwRec &R, int lane, u
 // EXACT = false: the hot path -- two single-edge candidates, local sets of <= 64 vertices whose split graph fits; anything
 // else sets need_exact and is left to the exact run.  EXACT = true: the whole of it (candidate search to the end, wide
 // evaluator), on a state nobody else changes meanwhile.
-template <int MAXT, bool ROWS128, bool EXACT>
+template <int MAXT, bool ROWS128, bool EXACT, bool SPARSE = false>
 __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds, int maxnw, u32 tv, u64 tt, u32 gchain, u64 seed, int lane, MwOut &O,
                                        u32 *stage, u32 rec_q, u32 *vis = nullptr, u32 wv = 0u, u32 q = 0u, u32 W = 0u, u64 guard_limit = 0x7FFFFFFFull)
 {
@@ -288,7 +321,9 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             const int k = (int)e1.k;
             int fres = 0;          // 1 = big->small is flipped, 2 = small->big
             R.id1 = (u32)idx; R.big1 = e1.big; R.small1 = e1.small;
-            const u32 wid_bs = e1.big * stride32 + (e1.small >> 5), wid_sb = e1.small * stride32 + (e1.big >> 5);   // the words of big->small, small->big
+            // the words (and bits) of big->small, small->big: of the rows, or of the pair's two bits in the chain's sparse record
+            const u32 wid_bs = SPARSE ? (u32)idx >> 4 : e1.big * stride32 + (e1.small >> 5), wid_sb = SPARSE ? wid_bs : e1.small * stride32 + (e1.big >> 5);
+            const u32 bit_bs = SPARSE ? ((u32)idx & 15u) * 2u : e1.small & 31u, bit_sb = SPARSE ? bit_bs + 1u : e1.big & 31u;
             if (k + 2 <= WAVE) {
                 O.Lv1 = load_list(C.nb, e1.nb_off, k, e1.big, e1.small, lane);
                 snap_point();
@@ -296,7 +331,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                 u64 myH = mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
                 { u32 z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); u32 Lz = O.Lv1; asm volatile("" : "+v"(Lz)); myH |= mw_build<ROWS128>(rr, stride32, Lz, k + 2, lane) & (u64)z; }
 #else
-                const u64 myH = mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
+                const u64 myH = SPARSE ? mw_build_sparse(rr, C.nb, e1.nb_off, k, (u32)idx, lane) : mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
 #endif
                 const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
                 const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);  // big->small, small->big
@@ -317,6 +352,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             if (go_wide) {
                 if constexpr (!EXACT) {
                     O.need_exact = 1u;
+                } else if constexpr (SPARSE) {
+                    fres = 0; R.sus |= 1u;   // (the sparse layout is only selected for graphs whose local sets always fit the fast evaluator)
                 } else {
                     fres = 0;
                     if (k + 2 > 64 * maxnw && C.xw && k + 2 <= 64 * FCM_XW_MAXNW) {   // 257..1024 local vertices
@@ -342,9 +379,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             }
             if (fres > 0 && !O.need_exact) {
                 R.nonempty = 1u;
-                const u32 cf = fres == 1 ? e1.big : e1.small, ct = fres == 1 ? e1.small : e1.big;
-                R.wid_clr = fres == 1 ? wid_bs : wid_sb; R.bit_clr = ct & 31u;
-                R.wid_set = fres == 1 ? wid_sb : wid_bs; R.bit_set = cf & 31u;
+                R.wid_clr = fres == 1 ? wid_bs : wid_sb; R.bit_clr = fres == 1 ? bit_bs : bit_sb;
+                R.wid_set = fres == 1 ? wid_sb : wid_bs; R.bit_set = fres == 1 ? bit_sb : bit_bs;
                 R.add_k = (u32)k; R.big_set = k + 2 > 48 ? 1u : 0u;
             }
         }
@@ -402,13 +438,15 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     } else {
                         O.Lv2 = load_list(C.nb, e2.nb_off, ck, e2.big, e2.small, lane);
                     }
-                    HB = mw_build<ROWS128>(rr, stride32, O.Lv2, ck + 2, lane);
+                    HB = SPARSE ? mw_build_sparse(rr, C.nb, e2.nb_off, ck, (u32)cand, lane) : mw_build<ROWS128>(rr, stride32, O.Lv2, ck + 2, lane);
                     f = (u32)(rdlane64(HB, ck + 1) >> ck) & 1u;
                     bwd = (u32)(rdlane64(HB, ck) >> (ck + 1)) & 1u;
                 } else {
                     if constexpr (!EXACT) {
                         O.need_exact = 1u;
                         break;
+                    } else if constexpr (SPARSE) {
+                        R.sus |= 1u;
                     } else {  // wide candidate: look at its two words directly
                         const u32 wf = mw_uni(C.rows[e2.big * stride32 + (e2.small >> 5)]), wb = mw_uni(C.rows[e2.small * stride32 + (e2.big >> 5)]);
                         f = (wf >> (e2.small & 31u)) & 1u;
@@ -430,7 +468,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             bool okd = true;
             if (!go_wide) {
                 O.Lv1 = load_list(C.nb, e1.nb_off, dk, e1.big, e1.small, lane);
-                HA = mw_build<ROWS128>(rr, stride32, O.Lv1, dk + 2, lane);
+                HA = SPARSE ? mw_build_sparse(rr, C.nb, e1.nb_off, dk, ed, lane) : mw_build<ROWS128>(rr, stride32, O.Lv1, dk + 2, lane);
                 // (1) remove the direction the coin picks from the reciprocal pair
                 const u32 ab = (u32)((rdlane64(HA, dk + 1) >> dk) & 1ull), ba = (u32)((rdlane64(HA, dk) >> (dk + 1)) & 1ull);
                 okd = (ab & ba) != 0u;
@@ -451,6 +489,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             if (go_wide) {
                 if constexpr (!EXACT) {
                     O.need_exact = 1u;
+                } else if constexpr (SPARSE) {
+                    R.sus |= 1u;
                 } else if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
                     if (C.xw && dk + 2 <= 64 * FCM_XW_MAXNW && rk + 2 <= 64 * FCM_XW_MAXNW) {
                         okd = xw_del(C.xw, C.rows, stride32, C.nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
@@ -473,8 +513,14 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             }
             if (!okd) R.sus |= 2u;  // slot list says reciprocal, bitmap says not
             R.nonempty = 1u; R.is_dmove = 1u;
-            R.wid_clr = dfrom * stride32 + (dto >> 5); R.bit_clr = dto & 31u;
-            R.wid_set = eb * stride32 + (ea >> 5); R.bit_set = ea & 31u;
+            if constexpr (SPARSE) {   // bit 2e: big -> small, 2e + 1: small -> big.  Deleted: the coin's direction of the reciprocal pair; added: the reverse of the single edge
+                const u32 bc = 2u * ed + (coin ? 0u : 1u), bs = 2u * (u32)cand + (rfwd ? 1u : 0u);
+                R.wid_clr = bc >> 5; R.bit_clr = bc & 31u;
+                R.wid_set = bs >> 5; R.bit_set = bs & 31u;
+            } else {
+                R.wid_clr = dfrom * stride32 + (dto >> 5); R.bit_clr = dto & 31u;
+                R.wid_set = eb * stride32 + (ea >> 5); R.bit_set = ea & 31u;
+            }
             R.dnew = (u32)cand;
             R.add_k = (u32)(dk + rk); R.big_set = (dk + 2 > 48 || rk + 2 > 48) ? 1u : 0u;
         }
@@ -532,7 +578,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
 
 // ---- out of line: the exact run.  Context from LDS; the record goes to the staging words like the hot path's, the
 // per-lane results (count changes, the two bitmap words) to the arc list's place.
-template <int MAXT, bool ROWS128>
+template <int MAXT, bool ROWS128, bool SPARSE = false>
 __device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 tv, u32 q, u32 stage_off)
 {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -547,7 +593,7 @@ __device__ __attribute__((noinline)) void mw_exact_call(u64 *smem, u32 wv, u32 t
     const u64 seed = (u64)rdlane(cv, MC_SEED) | ((u64)rdlane(cv, MC_SEED + 1) << 32);
     const u64 sampled0 = (u64)rdlane(cv, MC_SAMPLED0) | ((u64)rdlane(cv, MC_SAMPLED0 + 1) << 32);
     MwOut O;
-    mw_run<MAXT, ROWS128, true>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, O, (u32 *)smem + stage_off, q, nullptr, 0u, 0u, 0u,
+    mw_run<MAXT, ROWS128, true, SPARSE>(C, mine_lds, wide_lds, maxnw, tv, sampled0 + q, rdlane(cv, MC_GCHAIN), seed, lane, O, (u32 *)smem + stage_off, q, nullptr, 0u, 0u, 0u,
                                 (u64)rdlane(cv, MC_GUARD) | ((u64)rdlane(cv, MC_GUARD + 1) << 32));
     u32 *out = (u32 *)(mine_lds + 64);
     if (lane < 16) out[lane] = (u32)O.myd;
@@ -716,7 +762,7 @@ __device__ __attribute__((noinline)) void mw_fill_table(u64 *smem, u32 wv, u32 q
     wave_sync();
 }
 
-template <int MAXT, bool ROWS128>
+template <int MAXT, bool ROWS128, bool SPARSE = false>
 __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 {
     const u32 W = p.mw_waves;                              // waves per chain: 2, 4, 8 or 16 (blockDim.x / 64)
@@ -805,7 +851,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         MwOut O;
         u32 *stage = ringL + (q & ring) * MW_REC_WORDS;      // this proposal's record
         MW_T(t_snap);
-        mw_run<MAXT, ROWS128, false>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, O, stage, q, vis, wv, q, W, guard_limit);
+        mw_run<MAXT, ROWS128, false, SPARSE>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, O, stage, q, vis, wv, q, W, guard_limit);
         const u32 snap = O.snap;
         MW_T(t_run);
 
@@ -848,7 +894,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             // under the token nobody else can commit; once every earlier commit is in memory too, run it again, all of it
             { const u32 gone = q << 4; MW_LDS_ST32(mw_lds_addr(stage + SR_STATE), gone, "1"); }   // the staged record is void from here on
             while (mw_vis_min(vis, W, lane) < q) __builtin_amdgcn_s_sleep(1);
-            mw_exact_call<MAXT, ROWS128>(smem, wv, tv, q, (u32)(stage - (u32 *)smem));
+            mw_exact_call<MAXT, ROWS128, SPARSE>(smem, wv, tv, q, (u32)(stage - (u32 *)smem));
             const u32 *out = (const u32 *)(mine_lds + 64);
             const u32 xv = lane < 18 ? out[lane] : 0u;
             O.myd = lane < 16 ? (int)xv : 0;
@@ -959,10 +1005,10 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 }
 
 // (W is a launch parameter: the block is W x 64 threads.  8 waves per SIMD whatever W is: at most 64 VGPRs.)
-template <int MAXT, bool ROWS128>
+template <int MAXT, bool ROWS128, bool SPARSE = false>
 __global__ __launch_bounds__(16 * WAVE, MW_MINW) void fcm_step_mw_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];
     if (blockIdx.x >= p.nchains) return;
-    mw_wave<MAXT, ROWS128>(p, smem);
+    mw_wave<MAXT, ROWS128, SPARSE>(p, smem);
 }

@@ -3,7 +3,7 @@
 //   EXACT=1: the tracked depth tmax (= count entries - 2) IS FCM_MAXT, a compile-time constant: the
 //            clique walk has exactly that many levels and no depth checks (tags x2_0 .. x6_1);
 //   EXACT=0: tmax <= FCM_MAXT at run time (tags 6_0, 14_0, 6_1, 14_1).
-#if defined(FCM_PC) && FCM_PC >= 3
+#if defined(FCM_PC) && FCM_PC == 3
 #define MW_TBL_N 20u   // (the clique-move kernel: a shorter draw table, so that its workgroup stays within 10 KiB of LDS -- 16 per CU)
 #endif
 #include "fcm_kernels_common.hpp"
@@ -24,7 +24,7 @@
 #define FCM_MINW 1
 #endif
 
-#if defined(FCM_PC) && FCM_PC >= 3
+#if defined(FCM_PC) && FCM_PC == 3
 // tags c2_1 .. c6_1: the cooperative step kernel for move mixes with clique moves (fcm_step_cq.hpp): W = p->mw_waves (or 1)
 // waves per chain, the pairs of a move on the pre-move bitmap, one commit on accept
 extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
@@ -35,12 +35,13 @@ extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *
     return (int)hipGetLastError();
 }
 #elif defined(FCM_PC) && FCM_PC
-// tags m2_0 .. m6_0 (rows of one cache line, FCM_PC=1) and n2_0 .. n6_0 (longer rows, FCM_PC=2): the
+// tags m2_0 .. m6_0 (rows of one cache line, FCM_PC=1), n2_0 .. n6_0 (longer rows, FCM_PC=2) and s2_0 .. s6_0 (sparse state: two
+// bits per adjacent pair instead of row bitmaps, FCM_PC=5): the
 // multi-wave kernel (p->mw_waves waves per chain, in-order commit), simple moves only
 extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
 {
     const size_t words = fcm_mw_lds_words(p->maxnw, (int)p->mw_waves);
-    fcm_step_mw_kernel<FCM_MAXT, FCM_PC == 1><<<dim3(p->nchains), dim3(p->mw_waves * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
+    fcm_step_mw_kernel<FCM_MAXT, FCM_PC == 1, FCM_PC == 5><<<dim3(p->nchains), dim3(p->mw_waves * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
     return (int)hipGetLastError();
 }
 #else

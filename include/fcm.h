@@ -289,6 +289,11 @@ typedef struct {
                                   W consecutive proposals of a chain in flight, decided in order.  The library chooses (simple
                                   moves, <= 8 count entries; the largest W of 8, 4, 2 with chains x W <= 8192 wave slots; 16 on graphs of more than 1024 vertices whose builds touch many cache lines, or with up to 256 chains); environment FCM_MW=<W> overrides
                                   (1 = one-wave kernel).  Trajectories are identical whatever W is. */
+    uint32_t sparse_state;     /* 1: the chains' graphs are held as two bits per adjacent pair of pr(G) (the edgebits layout, src/io.rs:152-159)
+                                  instead of row bitmaps: chosen for graphs of more than 1024 vertices with local sets of at most 11
+                                  vertices and at most two common neighbours per pair on average, under the simple moves (BASELINE
+                                  configs[4]: 250 KB per chain instead of 115 MB).  Environment FCM_SPARSE=0 / 1 overrides.  Results do
+                                  not depend on it. */
 } fcm_sampler_info;
 int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out);
 /* The Bounds the sampler checks against (MCMCSampler::bounds, src/lib.rs:170). */
