@@ -59,6 +59,15 @@ def needed_bytes(d, n, mean_k):
     return evals * (s * lines * 128.0 + 16.0 + 4.0 * mean_k + 64.0) + 16.0 * int(d["n_empty"])
 
 
+def sparse_bytes(d, mean_k):
+    """Bytes a proposal has to move on the sparse per-chain state (two bits per adjacent pair): per evaluated
+    pair its 16-B table entry, 4k B of vertex list, its (k+2)(k+1)/2 local pair entries of 8 B (none for k = 0) and as many
+    dword gathers from the chain's record, plus the commit's read-modify-write; an empty proposal 16 B."""
+    t = (mean_k + 2.0) * (mean_k + 1.0) / 2.0
+    evals = int(d["n_flip"]) + 2 * int(d["n_dmove"])
+    return evals * (16.0 + 4.0 * mean_k + (8.0 * t if mean_k > 0 else 0.0) + 4.0 * t + 8.0) + 16.0 * int(d["n_empty"])
+
+
 def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
     """Times the CPU oracle (reference-faithful port: neighbourhood lookup,
     induced-subgraph recount before/after, revert from saved vectors) on the
@@ -297,7 +306,8 @@ def main():
         mean_k = float(d["sum_k"]) / max(1.0, float(d["n_flip"] + 2 * d["n_dmove"] + d["n_changes"]))
         survey_bytes = algorithmic_bytes(d, n) / args.steps             # per launch, this rank
         long_rows = n > 1024
-        abytes = needed_bytes(d, n, mean_k) / args.steps if long_rows else survey_bytes
+        sparse = bool(s.info.get("sparse_state", 0))
+        abytes = sparse_bytes(d, mean_k) / args.steps if sparse else (needed_bytes(d, n, mean_k) / args.steps if long_rows else survey_bytes)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         this_lib = lib_sha16(fcm.LIB_PATH)
         traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals, args.moves, this_lib)
@@ -328,7 +338,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": abytes,
-                         "algorithmic_model": "lines touched (rows longer than one 128-B line; DESIGN.md 4.3)" if long_rows else "SURVEY.md 8(d): whole rows",
+                         "algorithmic_model": ("sparse state: table entry + list + local pair entries + record gathers (DESIGN.md 2; the record lives in L2 / MALL)" if sparse
+                                               else ("lines touched (rows longer than one 128-B line; DESIGN.md 4.3)" if long_rows else "SURVEY.md 8(d): whole rows")),
+                         "sparse_state": sparse,
                          "survey_bytes_per_launch": survey_bytes,
                          "kernel": "fcm_step_mw_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel",
                          "waves_per_chain": int(s.info["waves_per_chain"])},

@@ -47,7 +47,7 @@ def test_config5_oracle_twins_on_the_graph_itself(fcm, oracle, cfg5):
     gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e, relaxation=0.0)
     assert gg.flagser_count() == go.flagser_count()
     s = fcm.MCMCSampler(gg, b_g, n_chains=2, seed=0, first_chain_id=100)
-    assert s.info["waves_per_chain"] == 16 and s.info["row_words"] == 480
+    assert s.info["waves_per_chain"] == 16 and s.info["row_words"] == 480 and s.info["sparse_state"] == 1
     tw = [oracle.Chain(go, b_o, seed=0, chain_id=100 + c) for c in range(2)]
     for nstep in (1, 2999, 57000):
         s.step(nstep)
@@ -59,12 +59,17 @@ def test_config5_oracle_twins_on_the_graph_itself(fcm, oracle, cfg5):
     assert (st["accepted"] < st["sampled"]).all(), "no rejection in 60000 proposals: the bounds were never tested"
 
 
-def test_config5_full_share_256_chains(fcm, cfg5):
-    """The stated per-GPU share: 256 chains (29 GB of bitmaps), 4096 proposals each; recount of three chains."""
+@pytest.mark.parametrize("sparse", ["1", "0"])
+def test_config5_full_share_256_chains(fcm, cfg5, monkeypatch, sparse):
+    """The stated per-GPU share: 256 chains x 4096 proposals, recount of three chains -- on the sparse state the library
+    picks for this graph (two bits per adjacent pair: 250 KB per chain) and on the row bitmaps north_star names (29 GB)."""
     n, e = cfg5
     g = fcm.Graph.from_edges(n, e)
+    if sparse == "0":
+        monkeypatch.setenv("FCM_SPARSE", "0")
     s = fcm.initialize_new_sampler(g, n_chains=256, seed=1)
-    assert s.info["bytes_per_chain"] * 256 > 28e9
+    assert s.info["sparse_state"] == int(sparse)
+    assert (s.info["bytes_per_chain"] * 256 < 1e8) if sparse == "1" else (s.info["bytes_per_chain"] * 256 > 28e9)
     s.step(4096)
     st = s.stats()
     assert (st["status"] == 0).all() and (st["sampled"] == 4096).all() and (st["accepted"] <= st["sampled"]).all()
