@@ -928,7 +928,11 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         const u32 nh = q + 1u;
         MW_LDS_ST32(mw_lds_addr(ctl), nh, "1");                                      // the token: after the entry and the counts, in order
         __builtin_amdgcn_s_setprio(0);
+#if MW_PROBE == 9   // (timing probe: no commit stores -- wrong results by design)
+        if (commit && q == 0xFFFFFFFFu) {
+#else
         if (commit) {
+#endif
             // the commit's stores (one value twice if both changes fall into one word: double-edge move only)
             const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
             const u32 bit_clr = 1u << ((flg >> 20) & 31u), bit_set = 1u << ((flg >> 25) & 31u);
