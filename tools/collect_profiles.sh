@@ -14,6 +14,13 @@ echo "== bench (full)"; timeout -k 10 400 python bench.py > $OUT/bench.json 2> $
 for K in 1 3 4; do echo "== bench config $K"; timeout -k 10 300 python bench.py --no-cpu-baseline --config $K --steps 8 > $OUT/bench_config$K.json 2> $OUT/bench_config$K.err || exit 1; done
 echo "== bench 256 chains"; timeout -k 10 300 python bench.py --no-cpu-baseline --chains 256 --steps 8 > $OUT/bench_config2_256chains.json 2> $OUT/bench_256.err || exit 1
 echo "== bench default mix"; timeout -k 10 300 python bench.py --no-cpu-baseline --moves default --steps 8 > $OUT/bench_default_mix.json 2> $OUT/bench_default_mix.err || exit 1
+for CH in 2048 1024 256; do   # the cooperative clique-move kernel (W = 2, 4, 8) and, beside it, the one-wave kernel on the same share
+  timeout -k 10 300 python bench.py --no-cpu-baseline --moves default --chains $CH --steps 8 > $OUT/bench_default_mix_${CH}chains.json 2> $OUT/bench_default_mix_$CH.err || exit 1
+  FCM_CQ=0 timeout -k 10 300 python bench.py --no-cpu-baseline --moves default --chains $CH --steps 8 > $OUT/bench_default_mix_${CH}chains_onewave.json 2> $OUT/bench_default_mix_${CH}o.err || exit 1
+done
+echo "== bench config 4: row bitmaps, and the sparse state with more chains"
+FCM_SPARSE=0 timeout -k 10 300 python bench.py --no-cpu-baseline --config 4 --steps 8 > $OUT/bench_config4_rowbitmaps.json 2> $OUT/bench_config4_rb.err || exit 1
+for CH in 1024 4096; do timeout -k 10 300 python bench.py --no-cpu-baseline --config 4 --chains $CH --steps 8 > $OUT/bench_config4_${CH}chains.json 2> $OUT/bench_config4_$CH.err || exit 1; done
 echo "== count kernel"; timeout -k 10 300 python tools/count_bench.py > $OUT/count_kernel.json 2> $OUT/count_kernel.err || echo "count bench failed"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 stats"
@@ -21,4 +28,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 cd $ROOT
 echo "== pmc"; bash tools/run_pmc.sh $TAG > $OUT/pmc.log 2>&1 && python tools/pmc_summary.py gpurun_out/pmc_$TAG $TAG $OUT/pmc_summary.json > /dev/null || exit 1
 echo "== sq"; bash tools/sq_quick.sh > $OUT/sq_counters.json 2> $OUT/sq.err || exit 1
+bash tools/sq_quick.sh --moves default --proposals 1024 > $OUT/sq_counters_default_mix.json 2> $OUT/sq_dm.err || exit 1
+bash tools/sq_quick.sh --moves default --chains 1024 --proposals 1024 > $OUT/sq_counters_default_mix_1024chains.json 2> $OUT/sq_dm1024.err || exit 1
 echo "== done"; ls $OUT
