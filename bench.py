@@ -342,7 +342,8 @@ def main():
                                                else ("lines touched (rows longer than one 128-B line; DESIGN.md 4.3)" if long_rows else "SURVEY.md 8(d): whole rows")),
                          "sparse_state": sparse,
                          "survey_bytes_per_launch": survey_bytes,
-                         "kernel": "fcm_step_mw_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel",
+                         "kernel": ("fcm_step_cq_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel") if (weights[2] > 0 or weights[3] > 0)
+                                   else ("fcm_step_mw_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel"),
                          "waves_per_chain": int(s.info["waves_per_chain"])},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 2 and args.moves == "simple":

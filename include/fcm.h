@@ -285,7 +285,10 @@ typedef struct {
     int32_t ncounts;
     int32_t lossless;          /* 1 if every reachable dimension is tracked */
     uint32_t n_chains;
-    uint32_t waves_per_chain;  /* 1: one wave per chain (fcm_step_kernel); W = 2, 4, 8, 16: the multi-wave kernel (fcm_step_mw_kernel),
+    uint32_t waves_per_chain;  /* Move mixes with clique moves: the waves that share a move's changed pairs in the cooperative kernel
+                                  (fcm_step_cq_kernel: 8 up to 512 chains, 4 up to 1024, 2 up to 2048; FCM_CQW overrides); 1 = the one-wave
+                                  kernel (more than 2048 chains, more than 8 count entries, or FCM_CQ=0).  Simple moves:
+                                  1: one wave per chain (fcm_step_kernel); W = 2, 4, 8, 16: the multi-wave kernel (fcm_step_mw_kernel),
                                   W consecutive proposals of a chain in flight, decided in order.  The library chooses (simple
                                   moves, <= 8 count entries; the largest W of 8, 4, 2 with chains x W <= 8192 wave slots; 16 on graphs of more than 1024 vertices whose builds touch many cache lines, or with up to 256 chains); environment FCM_MW=<W> overrides
                                   (1 = one-wave kernel).  Trajectories are identical whatever W is. */
@@ -304,6 +307,11 @@ int fcm_sampler_get_bounds(const fcm_sampler *s, fcm_bounds *out);
 /*   FCM_DEVICE=<d>            device of the legacy flagser_count_unweighted   */
 /*   FCM_MW=<1|2|4|8|16>       waves per chain of the step kernel (a tuning    */
 /*                             override: trajectories do not depend on it)     */
+/*   FCM_CQ=<0|1>              clique moves: 0 = the one-wave kernel, 1 = the       */
+/*                             cooperative kernel (default: cooperative up to 2048    */
+/*                             chains);  FCM_CQW=<1|2|4|8> its waves per chain        */
+/*   FCM_SPARSE=<0|1>          per-chain state as two bits per adjacent pair          */
+/*                             (fcm_sampler_info.sparse_state) off / on where possible */
 /*   FCM_TEST_GUARD_LIMIT=<v>  TEST HOOK: lowers the bound at which a local    */
 /*                             count is taken to risk passing 2^31 (DESIGN.md  */
 /*                             4.5), so that the tests can drive the guarded   */
