@@ -83,6 +83,12 @@
 #ifndef MW_SPIN_NEAR
 #define MW_SPIN_NEAR 1     // 1: the wave next in line (W >= 4) polls without dozing (+2 % on configs[4], neutral elsewhere)
 #endif
+#ifndef MW_SLEEP_FAR
+#define MW_SLEEP_FAR 10   // s_sleep argument (x 64 cycles) between polls of a wave (W >= 4) four or more decisions away from the token ...
+#endif
+#ifndef MW_SLEEP_MID
+#define MW_SLEEP_MID 4    // ... two or three away (0: no doze)
+#endif
 #ifndef MW_K_EVLOOP
 #define MW_K_EVLOOP 0
 #endif
@@ -694,8 +700,8 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
         }
         // not yet: doze by how far off the token is (a decision takes several hundred cycles)
         const u32 dist = q - h;
-        if (dist >= 4u) __builtin_amdgcn_s_sleep(10);
-        else if (dist >= 2u) __builtin_amdgcn_s_sleep(4);
+        if (dist >= 4u) __builtin_amdgcn_s_sleep(MW_SLEEP_FAR);
+        else if (dist >= 2u) { if (MW_SLEEP_MID) __builtin_amdgcn_s_sleep(MW_SLEEP_MID); }
         else if (MW_SPIN_NEAR == 0) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
@@ -879,7 +885,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
                 }
                 if (h == q) break;
 #ifdef MW_STAMP
-                st_acc[7] += 1;
+                st_acc[7] += 0;   // (W = 2 path: polls were counted here once; the slot now holds the token-tail split)
 #endif
                 // not yet: doze by how far off the token is (a decision takes several hundred cycles)
                 const u32 dist = q - h;
@@ -890,6 +896,9 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
         }
         MW_T(t_token);
+#ifdef MW_STAMP
+        const u32 handed = mw_uni(ctl[1]);
+#endif
         if (hit) {
             // under the token nobody else can commit; once every earlier commit is in memory too, run it again, all of it
             { const u32 gone = q << 4; MW_LDS_ST32(mw_lds_addr(stage + SR_STATE), gone, "1"); }   // the staged record is void from here on
@@ -927,6 +936,10 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         MW_T(t_dec2);
         const u32 nh = q + 1u;
         MW_LDS_ST32(mw_lds_addr(ctl), nh, "1");                                      // the token: after the entry and the counts, in order
+        MW_T(t_head);
+#ifdef MW_STAMP
+        if (lane == 0) ctl[1] = (u32)t_head;   // (diagnostic: when the token was passed on; the next holder measures the hand-over against it)
+#endif
         __builtin_amdgcn_s_setprio(0);
 #if MW_PROBE == 9   // (timing probe: no commit stores -- wrong results by design)
         if (commit && q == 0xFFFFFFFFu) {
@@ -951,10 +964,11 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             st_acc[0] += t_snap - t_start;     // table entry, vis publish (waits for this wave's earlier stores), snap
             st_acc[1] += t_run - t_snap;       // the proposal: lists, builds, evaluations
             st_acc[2] += t_token - t_run;      // staging, checks, waiting for the token
-            st_acc[3] += t_redo - t_token;     // exact re-run (when hit)
+            st_acc[3] += q ? (u64)((u32)t_token - handed) : 0ull;   // hand-over: from the previous holder's head store to this wave holding the token
             st_acc[4] += t_rel - t_redo;       // decision under the token
             st_acc[5] += 1;
             st_acc[6] += (t_dec1 - t_redo) | ((t_dec2 - t_dec1) << 32);   // decision split: LDS reads + check | stores
+            st_acc[7] += ((t_head - t_dec2) << 32) | ((t_rel - t_head) & 0xFFFFFFFFull);   // ... head store | commit's stores issued (after the token is gone)
         }
 #endif
 

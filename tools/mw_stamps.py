@@ -19,11 +19,13 @@ out = np.zeros((chains, 8), np.uint64)
 _ffi.check(_ffi.lib().fcm_sampler_debug_stamps(s._h, out.ctypes.data_as(_ffi.u64p)))
 tot = out.sum(axis=0).astype(float)
 names = ["table entry, vis publish (own stores), snap", "proposal: lists, builds, evaluations", "staging, checks, wait for the token",
-         "exact re-run (hits)", "decision under the token"]
+         "hand-over (head store -> next holder has the token)", "decision under the token"]
 cnt = tot[5]
 raw = out[:, 6].astype(np.uint64)
 d1 = float((raw & np.uint64(0xFFFFFFFF)).sum()) / cnt
 d2 = float((raw >> np.uint64(32)).sum()) / cnt
+r7 = out[:, 7].astype(np.uint64)
+print("  after the stores: head store %.0f, commit (token already passed on) %.0f cycles" % (float((r7 >> np.uint64(32)).sum()) / cnt, float((r7 & np.uint64(0xFFFFFFFF)).sum()) / cnt))
 print("config %d, %d chains, W=%d: %d proposals, %.1f polls per proposal; decision = %.0f (counts, bounds) + %.0f (stores) + rest (state word, head)" % (cfg, chains, s.info["waves_per_chain"], cnt, tot[7] / cnt, d1, d2))
 for i, nm in enumerate(names):
     print("  %-50s %9.0f cycles per proposal" % (nm, tot[i] / cnt))
