@@ -1,6 +1,7 @@
 """Randomized differential test: random small graphs, move mixes, bounds relaxations, chain counts, launch sizes and
 waves per chain against oracle twins (tolerance 0: counts, counters, edges, slot lists after every launch).  A dozen
-cases by default; FCM_FUZZ_CASES=<n> and FCM_FUZZ_SEED=<s> run a campaign (the round-2 campaign: 400 cases, seed 2)."""
+cases by default; FCM_FUZZ_CASES=<n> and FCM_FUZZ_SEED=<s> run a campaign (the round-2 campaign: 400 cases, seed 2; round 3:
+both clique-move kernels with W = 1, 2, 4, 8 and the sparse per-chain state are drawn too)."""
 import os
 import numpy as np
 import pytest
@@ -28,8 +29,12 @@ def _case(i):
     weights = [(0.5, 0.5, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (0.0, 1.0, 0.0, 0.0), (0.1, 0.1, 0.6, 0.2), (0.25, 0.25, 0.25, 0.25)][mix]
     W = [1, 2, 4, 8, 16][int(rng.integers(0, 5))]
     steps = [int(x) for x in rng.integers(1, 400, size=int(rng.integers(2, 5)))] + [int(rng.integers(400, 4000 if MEDIUM else 1500))]
-    return dict(n=n, p=p, gseed=int(rng.integers(0, 1 << 30)), weights=weights, W=W, steps=steps, chains=int(rng.integers(1, 5)),
-                seed=int(rng.integers(0, 1 << 30)), relaxation=float(rng.choice([0.01, 0.05, 0.3])), first=int(rng.integers(0, 1000)))
+    c = dict(n=n, p=p, gseed=int(rng.integers(0, 1 << 30)), weights=weights, W=W, steps=steps, chains=int(rng.integers(1, 5)),
+             seed=int(rng.integers(0, 1 << 30)), relaxation=float(rng.choice([0.01, 0.05, 0.3])), first=int(rng.integers(0, 1000)))
+    # round 3: which clique-move kernel (cooperative with W waves per chain, or the one-wave one), and the sparse per-chain
+    # state where the graph allows it (simple moves, local sets of at most 11 vertices)
+    c["cq"], c["cqw"], c["sparse"] = int(rng.integers(0, 4) > 0), [1, 2, 4, 8][int(rng.integers(0, 4))], int(rng.integers(0, 2))
+    return c
 
 
 @pytest.mark.parametrize("i", range(NCASES))
@@ -40,6 +45,9 @@ def test_random_case_against_oracle_twins(fcm, oracle, monkeypatch, i):
     if len(e) < 2:
         pytest.skip("empty graph")
     monkeypatch.setenv("FCM_MW", str(c["W"]))
+    monkeypatch.setenv("FCM_CQ", str(c["cq"]))
+    monkeypatch.setenv("FCM_CQW", str(c["cqw"]))
+    monkeypatch.setenv("FCM_SPARSE", str(c["sparse"]))
     bounds = None
     rng = np.random.default_rng([SEED0, i, 7])
     if rng.random() < 0.35:
