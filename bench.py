@@ -94,12 +94,25 @@ def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
 
 
 def lib_sha16(path):
-    """First 16 hex digits of the SHA-256 of the library file: what ties a profile to the build it was taken on."""
+    """What ties a profile to the build it was taken on: the first 16 hex digits of the SHA-256 over the library's SOURCES
+    (csrc/*.hpp, *.hip, *.cpp, the Makefile, include/fcm.h, in name order) -- the same after a rebuild, different after any
+    kernel or host edit.  A library loaded from somewhere else (FCM_LIB_PATH: a diagnostic build) gets its file's own hash
+    behind a "variant:" tag, which no committed profile carries."""
+    import glob
     import hashlib
     h = hashlib.sha256()
-    with open(path, "rb") as f:
-        for blk in iter(lambda: f.read(1 << 20), b""):
-            h.update(blk)
+    if os.environ.get("FCM_LIB_PATH"):
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 20), b""):
+                h.update(blk)
+        return "variant:" + h.hexdigest()[:16]
+    src = os.path.join(ROOT, "flag_complex_mcmc_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(src, "*.hpp")) + glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.cpp"))
+                   + [os.path.join(src, "Makefile"), os.path.join(ROOT, "include", "fcm.h")])
+    for fn in files:
+        h.update(os.path.basename(fn).encode() + b"\0")
+        with open(fn, "rb") as f:
+            h.update(f.read())
     return h.hexdigest()[:16]
 
 
