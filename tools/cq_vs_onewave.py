@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Debug aid: the cooperative clique-move kernel (fcm_step_cq) with W waves per chain against the one-wave kernel (FCM_CQ=0),
-launch sizes 1, 7, 100.  usage: dbg_cq.py [W ...]"""
+"""Check: the cooperative clique-move kernel (fcm_step_cq) with W waves per chain against the one-wave kernel (FCM_CQ=0),
+launch sizes 1, 7, 100.  usage: cq_vs_onewave.py [W ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
