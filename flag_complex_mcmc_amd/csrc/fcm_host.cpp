@@ -1119,7 +1119,7 @@ try {
         // one-wave kernel, which needs no patches, is 4 % ahead (9.1e7 vs 8.7e7): it stays the choice there.  FCM_CQ=1 / 0 forces
         // the one or the other.
         const char *cq = getenv("FCM_CQ");
-        s->use_cq = s->clique_moves && nc - 2 >= 2 && nc - 2 <= 6 && (cq ? atoi(cq) != 0 : C <= 2048);
+        s->use_cq = s->clique_moves && nc - 2 >= 2 && nc - 2 <= 6 && ct.orders <= 8 && (cq ? atoi(cq) != 0 : C <= 2048);   // (<= 8 count entries: cliques of <= 8 vertices, the kernel's tables)
         if (s->use_cq) {
             // W waves per chain share a move's pairs: as many as keep chains x W within the 4096 wave slots of 4 waves per SIMD
             // (128 VGPRs), at most 8 (a move changes about 6 pairs).  FCM_CQW=<1|2|4|8> overrides.
