@@ -38,6 +38,25 @@ def test_two_handles_on_two_threads_equal_one_handle(fcm, oracle):
     assert multi.flag_count(4) == tw.state.flag_count and (multi.edges(4) == tw.state.graph_edges()).all()
 
 
+def test_two_handles_default_move_mix(fcm, oracle):
+    """The reference's default mix (clique moves: the cooperative kernel and its per-chain slot index) sharded over two
+    handles on two threads: chain for chain the single-handle run."""
+    n = 200
+    e = fcm.graphs.random_with_p(n, 0.12, seed=4)
+    gg, go, bg, bo = setup_pair(fcm, oracle, n, e)
+    one = fcm.MCMCSampler(gg, bg, n_chains=5, seed=8, move_weights=fcm.MOVE_DISTRIBUTION)
+    multi = fcm.MultiDeviceSampler(gg, bg, 5, devices=[0, 0], seed=8, move_weights=fcm.MOVE_DISTRIBUTION)
+    for _ in range(2):
+        one.step(300)
+        multi.step(300)
+    assert (multi.flag_counts() == one.flag_counts()).all() and (multi.stats()["n_cperm"] == one.stats()["n_cperm"]).all()
+    for c in range(5):
+        assert (multi.edges(c) == one.edges(c)).all() and (multi.double_slots(c) == one.double_slots(c)).all()
+    tw = oracle.Chain(go, bo, weights=fcm.MOVE_DISTRIBUTION, seed=8, chain_id=3)
+    tw.step(600)
+    assert multi.flag_count(3) == tw.state.flag_count and (multi.edges(3) == tw.state.graph_edges()).all()
+
+
 def test_errors_are_per_thread(fcm, oracle):
     """fcm_last_error is thread-local: a failing call on one thread does not disturb a handle stepping on another."""
     n = 200
