@@ -834,9 +834,17 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 #else
 #define MW_T(x) do { } while (0)
 #endif
+#ifdef MW_TRACE   // (diagnostic build: a timeline of chain 0, proposals MW_TRACE .. MW_TRACE + 400 -- tools/mw_trace.py)
+#define MW_EV(type, extra) do { if (chain == 0u && q >= (u32)(MW_TRACE) && q < (u32)(MW_TRACE) + 400u && lane_id == 0) { \
+        const u64 t_ = __builtin_amdgcn_s_memtime(); const unsigned long long i_ = atomicAdd((unsigned long long *)&p.dbgbuf[0], 1ull); \
+        if (i_ + 1ull < (unsigned long long)p.nchains * 8ull) p.dbgbuf[1 + i_] = (t_ << 24) | ((u64)(q & 0xFFFFu) << 8) | ((u64)((extra) & 15u) << 4) | (u64)(type); } } while (0)
+#else
+#define MW_EV(type, extra) do { } while (0)
+#endif
     const int lane_id = lane;
     for (u32 q = wv; q < N; q += W) {
         MW_T(t_start);
+        MW_EV(1, 0);
         // (a fresh copy of the lane id per proposal: comparisons with it are recomputed where they are used -- one VALU each --
         // instead of being hoisted out of the loop into SGPR pairs that are then spilled and reloaded)
         int lane = lane_id;
@@ -860,6 +868,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         mw_run<MAXT, ROWS128, false, SPARSE>(C, Hp, nullptr, maxnw, tv, 0ull, 0u, 0ull, lane, O, stage, q, vis, wv, q, W, guard_limit);
         const u32 snap = O.snap;
         MW_T(t_run);
+        MW_EV(2, q - snap);
 
         // ---- before the token: everything the decision can have ready.  sv = the staged record (lane i = word i)
         u32 sv = lane < SR_WORDS ? stage[lane] : 0u;
@@ -896,6 +905,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
         }
         MW_T(t_token);
+        MW_EV(3, hit ? 2u : 0u);
 #ifdef MW_STAMP
         const u32 handed = mw_uni(ctl[1]);
 #endif
@@ -937,6 +947,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         const u32 nh = q + 1u;
         MW_LDS_ST32(mw_lds_addr(ctl), nh, "1");                                      // the token: after the entry and the counts, in order
         MW_T(t_head);
+        MW_EV(4, 0);
 #ifdef MW_STAMP
         if (lane == 0) ctl[1] = (u32)t_head;   // (diagnostic: when the token was passed on; the next holder measures the hand-over against it)
 #endif

@@ -31,6 +31,8 @@ __global__ __launch_bounds__(256) void probe(uint64_t *cyc, uint32_t *sink)
         if (KIND == 6) { uint32_t s1, s2; BODY32(asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(s1) : "v"(a)); asm volatile("v_readlane_b32 %0, %1, 9" : "=s"(s2) : "v"(c));) a += s1 + s2; }
         if (KIND == 7) { BODY32(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc"); ) }
         if (KIND == 8) { BODY32(asm volatile("v_ffbl_b32 %0, %1" : "=v"(a) : "v"(b)); asm volatile("v_ffbl_b32 %0, %1" : "=v"(c) : "v"(d));) }
+        if (KIND == 10) { BODY32(asm volatile("s_nop 0"); asm volatile("s_nop 0");) }
+        if (KIND == 11) { BODY32(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); asm volatile("s_waitcnt lgkmcnt(0)");) }
         if (KIND == 9) { uint32_t s1 = r, s2 = r + 1; BODY32(asm volatile("s_and_b32 %0, %0, %1" : "+s"(s1) : "s"(s2)); asm volatile("s_or_b32 %0, %0, %1" : "+s"(s2) : "s"(s1));) a += s1 + s2; }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
@@ -68,8 +70,16 @@ static void run(const char *name, int per_instr)
     hipFree(cyc); hipFree(sink);
 }
 
-int main()
+// `valu_probe scalar`: only the scalar kinds (for a --pmc SQ_INSTS_SALU pass: do s_nop and s_waitcnt count as SALU? each
+// wave issues REPS x 64 of them)
+int main(int argc, char **argv)
 {
+    if (argc > 1) {
+        run<9>("s_and/s_or", 2);
+        run<10>("s_nop 0", 2);
+        run<11>("s_waitcnt", 2);
+        return 0;
+    }
     run<0>("v_add_u32", 2);
     run<1>("v_and/or_b32", 2);
     run<2>("v_bcnt_u32_b32", 2);
