@@ -116,7 +116,7 @@ def lib_sha16(path):
     return h.hexdigest()[:16]
 
 
-def load_traffic(config, n_chains, proposals, moves, this_lib):
+def load_traffic(config, n_chains, proposals, moves, this_lib, sparse=None):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC summary of this same command
     (profiles/pmc_summary.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE
     passes), or (None, why).  A replay of a profiled run, not a measurement of this one: the source says so.  The
@@ -129,6 +129,8 @@ def load_traffic(config, n_chains, proposals, moves, this_lib):
         return None, None
     for rec in (recs if isinstance(recs, list) else [recs]):
         if rec.get("config", 2) == config and rec.get("n_chains") == n_chains and rec.get("moves", "simple") == moves:
+            if sparse is not None and bool(rec.get("sparse_state", False)) != bool(sparse):
+                continue            # (the record is of the other state layout: FCM_SPARSE)
             if rec.get("lib_sha16") != this_lib:
                 return None, "STALE: profiled build %s != this build %s (profiles/pmc_summary.json, %s)" % (rec.get("lib_sha16"), this_lib, rec.get("tag", "?"))
             scale = float(proposals) / float(rec.get("proposals") or proposals)
@@ -323,7 +325,7 @@ def main():
         abytes = sparse_bytes(d, mean_k) / args.steps if sparse else (needed_bytes(d, n, mean_k) / args.steps if long_rows else survey_bytes)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         this_lib = lib_sha16(fcm.LIB_PATH)
-        traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals, args.moves, this_lib)
+        traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals, args.moves, this_lib, sparse)
         out = {
             "metric": METRIC, "value": total_prop / elapsed, "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -834,10 +834,14 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 #else
 #define MW_T(x) do { } while (0)
 #endif
-#ifdef MW_TRACE   // (diagnostic build: a timeline of chain 0, proposals MW_TRACE .. MW_TRACE + 400 -- tools/mw_trace.py)
-#define MW_EV(type, extra) do { if (chain == 0u && q >= (u32)(MW_TRACE) && q < (u32)(MW_TRACE) + 400u && lane_id == 0) { \
-        const u64 t_ = __builtin_amdgcn_s_memtime(); const unsigned long long i_ = atomicAdd((unsigned long long *)&p.dbgbuf[0], 1ull); \
-        if (i_ + 1ull < (unsigned long long)p.nchains * 8ull) p.dbgbuf[1 + i_] = (t_ << 24) | ((u64)(q & 0xFFFFu) << 8) | ((u64)((extra) & 15u) << 4) | (u64)(type); } } while (0)
+#ifdef MW_TRACE   // (diagnostic build: a timeline of chain 0 from proposal MW_TRACE on -- tools/mw_trace.py.  Every wave writes its
+                  //  own slice of the stamp buffer with plain stores: no atomics, nothing to wait for)
+    u32 ev_n = 0u;
+    const u32 ev_cap = (u32)(((u64)p.nchains * 8ull) / W);
+#define MW_EV(type, extra) do { if (chain == 0u && q >= (u32)(MW_TRACE) && ev_n < ev_cap) { \
+        const u64 t_ = __builtin_amdgcn_s_memtime(); \
+        if (lane_id == 0) p.dbgbuf[(size_t)wv * ev_cap + ev_n] = (t_ << 24) | ((u64)(q & 0xFFFFu) << 8) | ((u64)((extra) & 15u) << 4) | (u64)(type); \
+        ++ev_n; } } while (0)
 #else
 #define MW_EV(type, extra) do { } while (0)
 #endif

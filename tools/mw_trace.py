@@ -19,8 +19,8 @@ s.step(4096)
 out = np.zeros((chains, 8), np.uint64)
 _ffi.check(_ffi.lib().fcm_sampler_debug_stamps(s._h, out.ctypes.data_as(_ffi.u64p)))
 flat = out.reshape(-1)
-nev = min(int(flat[0]), flat.size - 1)
-ev = flat[1:1 + nev]
+ev = flat[flat != 0]
+nev = ev.size
 t = (ev >> np.uint64(24)).astype(np.int64); q = ((ev >> np.uint64(8)) & np.uint64(0xFFFF)).astype(np.int64)
 x = ((ev >> np.uint64(4)) & np.uint64(15)).astype(np.int64); ty = (ev & np.uint64(15)).astype(np.int64)
 t0 = t.min()

@@ -43,7 +43,7 @@ for key in ("1", "2", "3", "4", "d2", "e2"):       # d2 / e2: the default move m
     bench = json.load(open("%s/c%s_FETCH_SIZE.json" % (d, key)))
     # the first launches are warm-up; all launches run the same number of proposals
     rec = {"tag": tag, "config": k, "moves": moves, "n_chains": bench["config"]["chains_per_gpu"], "proposals": bench["config"]["proposals_per_step"],
-           "kernel": bench["roofline"]["kernel"], "waves_per_chain": bench["roofline"]["waves_per_chain"], "lib_sha16": bench.get("lib_sha16"), "n": bench["config"]["n"],
+           "kernel": bench["roofline"]["kernel"], "waves_per_chain": bench["roofline"]["waves_per_chain"], "lib_sha16": bench.get("lib_sha16"), "sparse_state": bool(bench["roofline"].get("sparse_state", False)), "n": bench["config"]["n"],
            "launches_seen": len(sf), "FETCH_SIZE_KB_per_launch": sum(sf) / len(sf), "WRITE_SIZE_KB_per_launch": sum(sw) / len(sw),
            "fetch_correction": None, "fetch_correction_pattern": None, "fetch_corrections_measured": dict(corr_long, **{"128": fetch_corr}),
            "calib_write_bytes_per_dword_store": write_bytes_per_store,

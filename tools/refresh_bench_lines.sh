@@ -1,10 +1,12 @@
+#!/bin/bash
+# GPU box, after profiles/pmc_summary.json of the current build is in place: the bench lines again (they replay the traffic
+# of that summary), into gpurun_out/prof_<tag>/.  usage: bash tools/refresh_bench_lines.sh <tag>
 set -u
-OUT=gpurun_out/prof_r02b; mkdir -p $OUT
-export MW_STAMP_DIR=$GRAFT_REPO_ROOT/tools/_stamp/stampb
-( bash tools/mw_stamps.sh 2 4096; bash tools/mw_stamps.sh 2 256; bash tools/mw_stamps.sh 3 1024; bash tools/mw_stamps.sh 4 256 ) > $OUT/mw_stamps.txt 2>&1
+TAG=${1:-r03}
+OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 for K in 1 3 4; do timeout -k 10 300 python bench.py --no-cpu-baseline --config $K --steps 8 > $OUT/bench_config$K.json 2> $OUT/bench_config$K.err || exit 1; done
 timeout -k 10 300 python bench.py --no-cpu-baseline --chains 256 --steps 8 > $OUT/bench_config2_256chains.json 2> $OUT/b256.err || exit 1
-timeout -k 10 300 python bench.py --no-cpu-baseline --config 3 --chains 256 --steps 8 > $OUT/bench_config3_256chains.json 2> $OUT/b3256.err || exit 1
 timeout -k 10 300 python bench.py --no-cpu-baseline --moves default --steps 8 > $OUT/bench_default_mix.json 2> $OUT/bdef.err || exit 1
+FCM_SPARSE=0 timeout -k 10 300 python bench.py --no-cpu-baseline --config 4 --steps 8 > $OUT/bench_config4_rowbitmaps.json 2> $OUT/bench_config4_rb.err || exit 1
 echo done
