@@ -15,6 +15,7 @@ resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -66,6 +67,18 @@ def sparse_bytes(d, mean_k):
     t = (mean_k + 2.0) * (mean_k + 1.0) / 2.0
     evals = int(d["n_flip"]) + 2 * int(d["n_dmove"])
     return evals * (16.0 + 4.0 * mean_k + (8.0 * t if mean_k > 0 else 0.0) + 4.0 * t + 8.0) + 16.0 * int(d["n_empty"])
+
+
+def sparse_sector_bytes(d, mean_k):
+    """The same accesses at the granularity the memory system moves them: 64-B sectors on the read side, 32-B on the write
+    side (tools/pmc_calib.hip measures 32 B per scattered dword store).  A flip: its table entry, its vertex list, the
+    record sector of its pair (+ the sectors of its local pair entries and of their record gathers when k > 0); a double-edge
+    move: the slot word, the slot pair's and the candidate's table entries, and list + record sector for both pairs; an
+    empty proposal its table entry; a non-empty one two 32-B writes.  What the FETCH_SIZE / WRITE_SIZE counters should see."""
+    t = (mean_k + 2.0) * (mean_k + 1.0) / 2.0
+    extra = (math.ceil(8.0 * t / 64.0) * 64.0 + 64.0 * min(t, 4.0)) * min(1.0, mean_k)   # local pair entries + their gathers, in the share of pairs with k > 0
+    flips, dmoves = int(d["n_flip"]), int(d["n_dmove"])
+    return flips * (3 * 64.0 + extra + 64.0) + dmoves * (7 * 64.0 + 2 * extra + 64.0) + 64.0 * int(d["n_empty"])
 
 
 def cpu_baseline(n, edges, bounds_lists, seed, target_seconds=15.0):
@@ -357,6 +370,8 @@ def main():
                                                else ("lines touched (rows longer than one 128-B line; DESIGN.md 4.3)" if long_rows else "SURVEY.md 8(d): whole rows")),
                          "sparse_state": sparse,
                          "survey_bytes_per_launch": survey_bytes,
+                         **({"sector_model_bytes_per_launch": sparse_sector_bytes(d, mean_k) / args.steps,
+                             "traffic_over_sector_model": (traffic / (sparse_sector_bytes(d, mean_k) / args.steps)) if traffic else None} if sparse else {}),
                          "kernel": ("fcm_step_cq_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel") if (weights[2] > 0 or weights[3] > 0)
                                    else ("fcm_step_mw_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel"),
                          "waves_per_chain": int(s.info["waves_per_chain"])},
