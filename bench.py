@@ -37,14 +37,26 @@ CONFIGS = {
 }
 
 
-def algorithmic_bytes(d, n):
+def algorithmic_bytes(d, n, clique_pairs=None):
     """W = 8*ceil(n/64) bytes per row; non-empty flip reads
     (k+4) rows + 64 B of word updates, double-edge move (k1+k2+8) rows + 128 B,
-    an empty proposal 16 B."""
+    an empty proposal 16 B.  Clique moves, as the survey's formula stands: every changed directed edge one (k+2)-row
+    evaluation.  With clique_pairs = (changed vertex pairs, shared rows) -- the counters of the clique-move kernels,
+    FCM_STAT_PAIRS / FCM_STAT_SHARED_ROWS -- rows that are read once are charged once: a pair whose two directions both
+    change is ONE local build (the mean k over pairs taken as the mean over changed directions: k belongs to the pair),
+    and the rows of a permuted clique's own vertices, which every pair of that move has in its local set, count once per
+    move."""
     W = 8 * ((n + 63) // 64)
-    nchg = int(d.get("n_changes", 0))  # clique moves: every changed directed edge is one (k+2)-row evaluation
-    return (int(d["sum_k"]) + 4 * int(d["n_flip"]) + 8 * int(d["n_dmove"]) + 2 * nchg) * W \
-        + 64 * int(d["n_flip"]) + 128 * int(d["n_dmove"]) + 64 * nchg + 16 * int(d["n_empty"])
+    nchg = int(d.get("n_changes", 0))
+    rows_simple = int(d["sum_k"]) + 4 * int(d["n_flip"]) + 8 * int(d["n_dmove"]) + 2 * nchg   # (sum_k includes k per changed direction)
+    if clique_pairs is not None and nchg > 0:
+        pairs, shared = clique_pairs
+        # sum_k = (simple moves' k) + (clique moves' k per changed direction); the stats do not split it, the mean k does
+        k_simple = float(d["sum_k"]) / max(1.0, float(int(d["n_flip"]) + 2 * int(d["n_dmove"]) + nchg))
+        rows_clique_dir = (k_simple + 2.0) * nchg
+        rows_clique_pair = (k_simple + 2.0) * pairs - shared
+        rows_simple = rows_simple - rows_clique_dir + max(0.0, rows_clique_pair)
+    return rows_simple * W + 64 * int(d["n_flip"]) + 128 * int(d["n_dmove"]) + 64 * nchg + 16 * int(d["n_empty"])
 
 
 def needed_bytes(d, n, mean_k):
@@ -335,7 +347,10 @@ def main():
         survey_bytes = algorithmic_bytes(d, n) / args.steps             # per launch, this rank
         long_rows = n > 1024
         sparse = bool(s.info.get("sparse_state", 0))
-        abytes = sparse_bytes(d, mean_k) / args.steps if sparse else (needed_bytes(d, n, mean_k) / args.steps if long_rows else survey_bytes)
+        clique = weights[2] > 0 or weights[3] > 0
+        # clique moves: rows that are read once are charged once (a sampler with clique moves counts pairs and shared rows in slots 14, 15)
+        clique_bytes = algorithmic_bytes(d, n, (float(d["n_recheck"]), float(d["n_held"]))) / args.steps if clique else None
+        abytes = sparse_bytes(d, mean_k) / args.steps if sparse else (needed_bytes(d, n, mean_k) / args.steps if long_rows else (clique_bytes if clique else survey_bytes))
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         this_lib = lib_sha16(fcm.LIB_PATH)
         traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals, args.moves, this_lib, sparse)
@@ -356,7 +371,8 @@ def main():
             "mean_k": mean_k,
             "clique_move_fraction": float(d["n_cperm"] + d["n_cswap"]) / float(d["sampled"]),
             "changed_edges_per_clique_move": float(d["n_changes"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"])),
-            "rare_paths_per_1e6": {k: 1e6 * float(d[k]) / float(d["sampled"]) for k in ("n_redo", "n_wide", "n_big", "n_recheck", "n_held")},
+            "rare_paths_per_1e6": {k: 1e6 * float(d[k]) / float(d["sampled"]) for k in (("n_redo", "n_wide", "n_big") + (() if clique else ("n_recheck", "n_held")))},
+            **({"changed_pairs_per_clique_move": float(d["n_recheck"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"]))} if clique else {}),
             "count_histogram_dim2_distinct": int(len(fdist.count_histogram(all_counts, 2)[0])),
             "parity": "counts == full GPU recount on 3 chains; oracle parity in tests/ -m gpu",
             "gathered_chains": int(all_counts.shape[0]),
@@ -367,7 +383,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": abytes,
                          "algorithmic_model": ("sparse state: table entry + list + local pair entries + record gathers (DESIGN.md 2; the record lives in L2 / MALL)" if sparse
-                                               else ("lines touched (rows longer than one 128-B line; DESIGN.md 4.3)" if long_rows else "SURVEY.md 8(d): whole rows")),
+                                               else ("lines touched (rows longer than one 128-B line; DESIGN.md 4.3)" if long_rows
+                                                     else ("SURVEY.md 8(d) whole rows, a clique move's rows charged once: one build per changed pair, the clique's own rows once per move (DESIGN.md 4.3)" if clique
+                                                           else "SURVEY.md 8(d): whole rows"))),
                          "sparse_state": sparse,
                          "survey_bytes_per_launch": survey_bytes,
                          **({"sector_model_bytes_per_launch": sparse_sector_bytes(d, mean_k) / args.steps,

@@ -274,7 +274,11 @@ class MCMCSampler:
     def stats(self):
         out = np.zeros((self.n_chains, _ffi.NSTATS), np.uint64)
         check(lib().fcm_sampler_get_stats(self._h, out.ctypes.data_as(u64p)))
-        return {name: out[:, i].copy() for i, name in enumerate(_ffi.STAT_NAMES)}
+        d = {name: out[:, i].copy() for i, name in enumerate(_ffi.STAT_NAMES)}
+        # slots 14 and 15 under the names they have on a sampler with clique moves (include/fcm.h: FCM_STAT_PAIRS,
+        # FCM_STAT_SHARED_ROWS); on a simple-move sampler they are n_recheck and n_held
+        d["n_pairs"], d["n_shared_rows"] = d["n_recheck"], d["n_held"]
+        return d
 
     @property
     def sampled(self):
@@ -439,7 +443,7 @@ class MultiDeviceSampler:
 
     def stats(self):
         parts = self._parallel(lambda r: self.shards[r].stats())
-        return {k: np.concatenate([p[k] for p in parts]) for k in _ffi.STAT_NAMES}
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
 
     def locate(self, chain):
         for r, (lo, hi) in enumerate(self.ranges):

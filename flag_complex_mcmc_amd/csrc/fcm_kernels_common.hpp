@@ -957,7 +957,9 @@ __device__ __forceinline__ void wide_add(const Wide W, const u32 *rows, u32 stri
 __device__ __forceinline__ u32 mw_lds_addr_of(const void *p) { return (u32)(size_t)(__attribute__((address_space(3))) const char *)p; }
 // tallies of the one-wave kernel, u32 words in LDS: counters in words 0..9 (the first eight count events), then the OR
 // of "count entry d was non-zero after a transition" masks and of the proposals' status words
-enum { OT_ACCEPTED = 0, OT_EMPTY, OT_FLIP, OT_DMOVE, OT_CPERM, OT_CSWAP, OT_WIDE, OT_BIG, OT_SUMK, OT_CHANGES, OT_NZ, OT_STATUS };
+enum { OT_ACCEPTED = 0, OT_EMPTY, OT_FLIP, OT_DMOVE, OT_CPERM, OT_CSWAP, OT_WIDE, OT_BIG, OT_SUMK, OT_CHANGES, OT_NZ, OT_STATUS,
+       OT_PAIRS, OT_SHARED };   // clique moves: vertex pairs with a changed direction (one local build each); (pairs - 1) x clique size: rows of the
+                                // clique's own vertices that the builds of one move read more than once
 #define FCM_TALLY_LDS_WORDS 56u   // u64 words: tallies (8), then the chain's counts and bounds E[16] = {count, min, max}
 
 // Step kernel
@@ -1067,6 +1069,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 
             bool nonempty = false, used_wide = false, used_xw = false;
             u32 t_sumk = 0u, t_changes = 0u, t_big = 0u, t_wide = 0u, pst = 0u, acc_inc = 0u;   // this proposal's share of the tallies
+            u32 t_pairs = 0u, t_shared = 0u;
             // pending commit (uniform)
             u32 c_clr_from = 0, c_clr_to = 0, c_set_from = 0, c_set_to = 0;
             // the two bitmap words a commit rewrites, read while the build is in flight so that the
@@ -1285,6 +1288,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                         wide_d = cr.wide_d;
                         t_sumk += (u32)cr.sum_k;
                         t_changes += (u32)cr.nchg;
+                        if (cr.npairs > 0) { t_pairs = (u32)cr.npairs; t_shared = move == 2 ? (u32)(cr.npairs - 1) * (u32)cr.n_d : 0u; }   // (a permutation's pairs all lie inside the clique)
                     }
                 } else {
                     pst |= 4u;  // this kernel variant was built without the clique moves
@@ -1370,16 +1374,20 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
                     }
                 }
             }
-            {   // this proposal's tallies: lanes 0..9 add, lanes 10..11 OR (all 64 lanes are active here: uniform branches only)
+            {   // this proposal's tallies: lanes 0..9 and 12..13 add, lanes 10..11 OR (all 64 lanes are active here: uniform branches only)
                 const u32 kind = !nonempty ? (1u << OT_EMPTY) : (move == 2 ? (1u << OT_CPERM) : (move == 3 ? (1u << OT_CSWAP) : (is_dmove ? (1u << OT_DMOVE) : (1u << OT_FLIP))));
                 const u64 im = (u64)(kind | (acc_inc << OT_ACCEPTED) | (t_big << OT_BIG));
                 u32 inc = lane_in(im) ? 1u : 0u;
                 inc = lane_in(1ull << OT_WIDE) ? t_wide : inc;
                 inc = lane_in(1ull << OT_SUMK) ? t_sumk : inc;
                 inc = lane_in(1ull << OT_CHANGES) ? t_changes : inc;
+                if constexpr (CLIQUE != 0) {
+                    inc = lane_in(1ull << OT_PAIRS) ? t_pairs : inc;
+                    inc = lane_in(1ull << OT_SHARED) ? t_shared : inc;
+                }
                 const u32 orv = lane_in(1ull << OT_NZ) ? (u32)nzm : pst;
                 const u32 taddr = mw_lds_addr_of(tly) + (u32)lane * 4u;
-                asm volatile("s_mov_b64 exec, 0x3ff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0xc00\n\tds_or_b32 %0, %2\n\ts_mov_b64 exec, -1"
+                asm volatile("s_mov_b64 exec, 0x33ff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0xc00\n\tds_or_b32 %0, %2\n\ts_mov_b64 exec, -1"
                              :: "v"(taddr), "v"(inc), "v"(orv) : "memory");
             }
             FCM_STAMP_AT(6);                                           // reductions, bounds, commit
@@ -1398,6 +1406,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         st_g[4] += rdlane(tl, OT_DMOVE); st_g[5] += rdlane(tl, OT_SUMK); if (nlen > st_g[6]) st_g[6] = nlen; st_g[7] |= stw;
         st_g[8] += rdlane(tl, OT_CPERM); st_g[9] += rdlane(tl, OT_CSWAP); st_g[10] += rdlane(tl, OT_CHANGES);
         st_g[12] += rdlane(tl, OT_WIDE); st_g[13] += rdlane(tl, OT_BIG);
+        if constexpr (CLIQUE != 0) { st_g[14] += rdlane(tl, OT_PAIRS); st_g[15] += rdlane(tl, OT_SHARED); }   // (a simple-move sampler: the multi-wave kernel's n_recheck, n_held)
 #ifdef FCM_STAMP
         for (int q = 0; q < 8; ++q) p.dbgbuf[(size_t)chain * 8 + q] += stamp_acc[q];
 #endif

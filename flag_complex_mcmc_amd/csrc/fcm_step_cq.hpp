@@ -29,7 +29,7 @@
 //     shared words | ring (record 0 = where a simple move's exact run leaves its record) | wave 0: Hp, arc list, draw table, tallies | wide evaluator
 //   tables (clique buckets, order thresholds) | tallies + the setup's scalars | dix | deferred pairs | per-wave sums [W][16] | clique arrays
 //   | Hp + arc list of the waves 1 .. W-1
-#define CQ_TALLY_WORDS 8u   // OT_* (12 u32), then the last setup's nchg, npairs, status, n_d
+#define CQ_TALLY_WORDS 9u   // OT_* (14 u32), then the last setup's nchg, npairs, status, n_d
 #define CQ_ORDERS 8         // clique orders the kernel takes (<= 8 count entries means cliques of <= 8 vertices)
 #define CQ_TABLE_WORDS (4u * CQ_ORDERS + 4u)   // cl_base | cl_count | clp_base | cumo | clq, clq_pairs, (cl_orders, chg_cap), spare
 #define CQ_DIX_WORDS 128u   // one byte per vertex of a graph of <= 1024 vertices: its index in d, plus one
@@ -64,7 +64,7 @@ __device__ __forceinline__ CqLds cq_carve(u64 *smem, int maxnw, u32 W, u32 chg_c
     L.hp_more = cl + fcm_clique_lds_words(chg_cap);
     return L;
 }
-enum { CS_NCHG = 12, CS_NPAIRS, CS_STATUS, CS_ND };   // u32 words of the tally block the setup leaves its scalars in
+enum { CS_NCHG = 14, CS_NPAIRS, CS_STATUS, CS_ND };   // u32 words of the tally block the setup leaves its scalars in
 enum { PS_STATUS = 16, PS_SUMK = 17 };               // u32 words of a wave's sums behind its 16 count changes
 
 // ---- out of line (wave 0): the proposal of a clique move (clique_setup) with its context from LDS; what it finds goes
@@ -372,7 +372,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
         const bool inb = ballot(cl && (c0 < mn || c0 > mx)) == 0ull;
         if (lane < 9) { ent[lane * 4 + 0] = c0; ent[lane * 4 + 1] = (lane == 0 && inb) ? 1ull : 0ull; ent[lane * 4 + 2] = mn; ent[lane * 4 + 3] = mx; }
         if (lane < 16) vis[lane] = MW_NONE;
-        if (lane < 16) tly[lane] = 0u;
+        if (lane < 18) tly[lane] = 0u;
         for (u32 i = (u32)lane; i < CQ_DIX_WORDS; i += WAVE) ((u64 *)L.dix)[i] = 0ull;
         if (lane == 0) {
             ctl[0] = 0u;
@@ -410,7 +410,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
         int myd = 0;                       // lane d: the change of count[d]
         long long wide_d = 0;              // ... its share that came through a 64-bit evaluator
         u32 nonempty = 0u, pst = 0u;
-        u32 t_sumk = 0u, t_changes = 0u, t_wide = 0u, t_big = 0u, kind = 1u << OT_EMPTY;
+        u32 t_sumk = 0u, t_changes = 0u, t_wide = 0u, t_big = 0u, t_pairs = 0u, t_shared = 0u, kind = 1u << OT_EMPTY;
         int npairs = 0;
         u32 sv = 0u, w_clr = 0u, w_set = 0u;
 
@@ -442,7 +442,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
                 }
             }
             barrier();                                                           // the pair list is there
-            const u32 csv = lane < 16 ? tly[lane] : 0u;
+            const u32 csv = lane < 18 ? tly[lane] : 0u;
             const int nchg = (int)rdlane(csv, CS_NCHG), n_d = (int)rdlane(csv, CS_ND);
             pst = rdlane(csv, CS_STATUS);
             if (nchg > 0) {
@@ -482,6 +482,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
                 if (wv == 0) {
                     pst |= my_status;
                     t_sumk = my_sumk; t_changes = (u32)nchg;
+                    if (npairs > 0) { t_pairs = (u32)npairs; t_shared = move == 2 ? (u32)(npairs - 1) * (u32)n_d : 0u; }   // (a permutation's pairs all lie inside the clique)
                     // the pairs left over for the wide evaluators, one by one
                     const u32 ndefer = mw_uni(L.defer[0]);
                     if (ndefer) {
@@ -553,16 +554,18 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
                 if (lane < (int)nd) L.dix[CL.d[lane]] = 0;
                 wave_sync();
             }
-            {   // tallies (OT_*): lanes 0..9 add, lanes 10..11 OR
+            {   // tallies (OT_*): lanes 0..9 and 12..13 add, lanes 10..11 OR
                 const u32 acc_inc = commit | ((nonempty ^ 1u) & in_bounds);        // an empty transition is accepted iff the state is inside the bounds (:186-187)
                 const u64 im = (u64)(kind | (acc_inc << OT_ACCEPTED) | (t_big << OT_BIG));
                 u32 inc = lane_in(im) ? 1u : 0u;
                 inc = lane_in(1ull << OT_WIDE) ? t_wide : inc;
                 inc = lane_in(1ull << OT_SUMK) ? t_sumk : inc;
                 inc = lane_in(1ull << OT_CHANGES) ? t_changes : inc;
+                inc = lane_in(1ull << OT_PAIRS) ? t_pairs : inc;
+                inc = lane_in(1ull << OT_SHARED) ? t_shared : inc;
                 const u32 orv = lane_in(1ull << OT_NZ) ? nzm : pst;
                 const u32 taddr = mw_lds_addr(tly) + (u32)lane * 4u;
-                asm volatile("s_mov_b64 exec, 0x3ff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0xc00\n\tds_or_b32 %0, %2\n\ts_mov_b64 exec, -1"
+                asm volatile("s_mov_b64 exec, 0x33ff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0xc00\n\tds_or_b32 %0, %2\n\ts_mov_b64 exec, -1"
                              :: "v"(taddr), "v"(inc), "v"(orv) : "memory");
             }
             if (W > 1u && commit) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the commit's stores are in memory before the other waves go on
@@ -585,6 +588,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
         st_g[4] += rdlane(tl, OT_DMOVE); st_g[5] += rdlane(tl, OT_SUMK); if (nlen > st_g[6]) st_g[6] = nlen; st_g[7] |= stw;
         st_g[8] += rdlane(tl, OT_CPERM); st_g[9] += rdlane(tl, OT_CSWAP); st_g[10] += rdlane(tl, OT_CHANGES);
         st_g[12] += rdlane(tl, OT_WIDE); st_g[13] += rdlane(tl, OT_BIG);
+        st_g[14] += rdlane(tl, OT_PAIRS); st_g[15] += rdlane(tl, OT_SHARED);
     }
 }
 

@@ -204,6 +204,11 @@ int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 #define FCM_STAT_BIG 13       /* evaluated local sets of more than 48 vertices (second trip of the whole-row build) */
 #define FCM_STAT_RECHECK 14   /* multi-wave kernel, W >= 4: proposals that had to check a record again under the token (it was decided on an exact run after they had checked it as staged) */
 #define FCM_STAT_HELD 15      /* multi-wave kernel, W >= 4: proposals that waited for the decision of a staged record in conflict with their reads */
+/* Samplers with clique moves run other kernels, which have neither; there the two slots count what the traffic model of a
+ * clique move needs (bench.py): */
+#define FCM_STAT_PAIRS 14        /* clique moves: vertex pairs with a changed direction (one local build each; FCM_STAT_CHANGES counts directions) */
+#define FCM_STAT_SHARED_ROWS 15  /* clique_permute: (changed pairs - 1) x clique order per move -- rows of the clique's own vertices that the builds
+                                    of one move read more than once */
 int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out);
 
 /* Directed edge list of one chain's current graph, ascending (from,to). */

@@ -108,3 +108,30 @@ def test_library_picks_the_kernel_by_chain_count(fcm, monkeypatch):
         assert (s.stats()["status"] == 0).all()
         c = chains - 1
         assert s.graph(c).flagser_count() == s.flag_count(c)[: len(s.graph(c).flagser_count())]
+
+
+def _sampler(fcm, g, weights, n_chains, seed, relaxation=0.01):
+    fc = g.flagser_count()
+    b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, relaxation))
+    return fcm.MCMCSampler(g, b, n_chains=n_chains, seed=seed, move_weights=weights)
+
+
+def test_pair_and_shared_row_counters_agree_between_the_two_kernels(fcm, monkeypatch):
+    """FCM_STAT_PAIRS / FCM_STAT_SHARED_ROWS (what bench.py's traffic model of a clique move is made of): a changed pair has
+    one or two changed directions; a permutation of a clique of c vertices with m changed pairs shares (m - 1) c rows;
+    both clique-move kernels count the same."""
+    n = 120
+    e = fcm.graphs.random_with_p(n, 0.2, seed=3)
+    g = fcm.Graph.from_edges(n, e)
+    got = []
+    for cq, w in (("0", "1"), ("1", "4")):
+        monkeypatch.setenv("FCM_CQ", cq)
+        monkeypatch.setenv("FCM_CQW", w)
+        s = _sampler(fcm, g, (0.0, 0.0, 0.7, 0.3), 3, 2)
+        s.step(800)
+        st = s.stats()
+        assert (st["status"] == 0).all()
+        assert (st["n_pairs"] <= st["n_changes"]).all() and (st["n_changes"] <= 2 * st["n_pairs"]).all() and (st["n_pairs"] > 500).all()
+        assert (st["n_shared_rows"] > 0).all() and (st["n_shared_rows"] < 8 * st["n_pairs"]).all()   # (cliques of at most 8 vertices here)
+        got.append((st["n_pairs"].tolist(), st["n_shared_rows"].tolist(), st["n_changes"].tolist()))
+    assert got[0] == got[1]
