@@ -694,27 +694,37 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
                 else held = true;                                                   // only staged: it may yet be dropped -- wait
             }
         }
-        if (h == q) {
-            if (hit || done == all) break;
-            continue;                 // the token is here: the records that held the checks up are decided now
+        auto doze = [&](u32 dist) {   // by how far off the token is (a decision takes several hundred cycles)
+            if (dist >= 4u) __builtin_amdgcn_s_sleep(MW_SLEEP_FAR);
+            else if (dist >= 2u) { if (MW_SLEEP_MID) __builtin_amdgcn_s_sleep(MW_SLEEP_MID); }
+            else if (MW_SPIN_NEAR == 0) __builtin_amdgcn_s_sleep(1);
+        };
+        if (hit || done == all) {
+            // nothing left to check (the rule, long before the token arrives): a plain wait -- the path from the poll that
+            // finds head == q to the decision is what the chain's other waves wait for, instruction by instruction
+            u32 hh = h;
+#pragma nounroll
+            while (hh != q) {
+                doze(q - hh);
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(hv), "=&v"(st) : "v"(a_head), "v"(a_state) : "memory");
+                hh = mw_uni(hv);
+            }
+            break;
         }
-        // not yet: doze by how far off the token is (a decision takes several hundred cycles)
-        const u32 dist = q - h;
-        if (dist >= 4u) __builtin_amdgcn_s_sleep(MW_SLEEP_FAR);
-        else if (dist >= 2u) { if (MW_SLEEP_MID) __builtin_amdgcn_s_sleep(MW_SLEEP_MID); }
-        else if (MW_SPIN_NEAR == 0) __builtin_amdgcn_s_sleep(1);
+        if (h == q) continue;         // the token is here: the records that held the checks up are decided now
+        doze(q - h);
     }
     __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
-    if (!hit) {
-        // (st: read after head == q was -- final)
-        u64 again = ballot((st & (MS_REDONE | MS_ACCEPTED)) == (MS_REDONE | MS_ACCEPTED)) & all;
-        if (again && lane == 0) atomicAdd(&tally[0], 1u);
-        while (again && !hit) {
-            const u32 i = (u32)__ffsll((long long)again) - 1u;
-            again &= again - 1ull;
-            const u32 ev = lane < SR_WORDS ? ringL[((snap + i) & ring) * MW_REC_WORDS + lane] : 0u;
-            hit = touches(ev);
-        }
+    if (hit) return 1u;
+    // (st: read after head == q was -- final)
+    u64 again = ballot((st & (MS_REDONE | MS_ACCEPTED)) == (MS_REDONE | MS_ACCEPTED)) & all;
+    if (again == 0ull && !held) return 0u;       // the rule: one scalar branch between the token and the decision
+    if (again && lane == 0) atomicAdd(&tally[0], 1u);
+    while (again && !hit) {
+        const u32 i = (u32)__ffsll((long long)again) - 1u;
+        again &= again - 1ull;
+        const u32 ev = lane < SR_WORDS ? ringL[((snap + i) & ring) * MW_REC_WORDS + lane] : 0u;
+        hit = touches(ev);
     }
     if (held && lane == 0) atomicAdd(&tally[1], 1u);
     return hit ? 1u : 0u;
@@ -880,10 +890,11 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 
         // ---- in-order decision.  While waiting for the token, hold the records snap..q-1 against this proposal's reads.
         bool hit = O.need_exact != 0u;
+        u32 hitw;                                 // the same as one scalar word (as a lane mask it costs two spilled SGPRs and a select per use)
         const u32 nent = q - snap;                                            // <= 2W - 1
         if (nent >= MW_VEC_MIN) {
             // several records: all at once and as soon as they are staged (out of line, W >= 4)
-            hit = mw_wait_staged(smem, wv, q, snap, O.Lv1, O.Lv2, hit ? 1u : 0u, W, sv) != 0u;
+            hitw = mw_uni(mw_wait_staged(smem, wv, q, snap, O.Lv1, O.Lv2, hit ? 1u : 0u, W, sv));   // (0 / 1, wave-uniform, and said so: what follows branches on it with scalar branches)
         } else {
             // few records (W = 2 always): each is looked at once, when it is decided
             const u32 cx0 = rdlane(sv, SR_CX0), cx1 = rdlane(sv, SR_CX1), dslot = rdlane(sv, SR_DSLOT);
@@ -907,13 +918,15 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
                 else __builtin_amdgcn_s_sleep(MW_SLEEP_NEAR);
             }
             __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
+            hitw = mw_uni(hit ? 1u : 0u);
         }
+        asm volatile("" : "+s"(hitw));            // (opaque, or hipcc folds it back into the mask)
         MW_T(t_token);
-        MW_EV(3, hit ? 2u : 0u);
+        MW_EV(3, hitw << 1);
 #ifdef MW_STAMP
         const u32 handed = mw_uni(ctl[1]);
 #endif
-        if (hit) {
+        if (hitw) {
             // under the token nobody else can commit; once every earlier commit is in memory too, run it again, all of it
             { const u32 gone = q << 4; MW_LDS_ST32(mw_lds_addr(stage + SR_STATE), gone, "1"); }   // the staged record is void from here on
             while (mw_vis_min(vis, W, lane) < q) __builtin_amdgcn_s_sleep(1);
@@ -940,13 +953,15 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         const u32 nonempty = flg & SRF_NONEMPTY, is_dmove = (flg >> 1) & 1u;
         const u64 ncnt = cnt + (u64)(long long)O.myd;
         const u64 outside = ballot(ncnt < bmin) | ballot(ncnt > bmax);         // (two compares into SGPR pairs and a scalar OR)
-        const u32 commit = outside == 0ull ? nonempty : 0u;
+        u32 commit;                                                            // = outside == 0 ? nonempty : 0, kept on the scalar side (hipcc goes through a VGPR and back)
+        asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(commit) : "s"(outside), "s"(nonempty) : "scc");
         MW_T(t_dec1);
         const u32 ebase = mw_lds_addr(ent) + eoff;
         if (commit) MW_LDS_ST64(ebase, ncnt, "0xff");
-        const u32 fin = (q << 4) | (hit ? MS_REDONE : 0u) | (commit ? MS_ACCEPTED : 0u) | MS_DECIDED;   // the record's state word
+        static_assert(MS_REDONE == 8u && MS_ACCEPTED == 4u, "state word: flags by shifts");
+        const u32 fin = (q << 4) | (hitw << 3) | (commit << 2) | MS_DECIDED;   // the record's state word
         MW_LDS_ST32(mw_lds_addr(stage + SR_STATE), fin, "1");
-        if (commit && !in_bounds) { const u32 one = 1u; MW_LDS_ST32(ebase + 8u, one, "1"); }
+        if (commit & (in_bounds ^ 1u)) { const u32 one = 1u; MW_LDS_ST32(ebase + 8u, one, "1"); }
         MW_T(t_dec2);
         const u32 nh = q + 1u;
         MW_LDS_ST32(mw_lds_addr(ctl), nh, "1");                                      // the token: after the entry and the counts, in order
@@ -991,7 +1006,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // the low four flag bits are the lanes of their counters as they stand -- lanes 0..8 OR into the flags.
         {
             const u32 acc_inc = commit | ((nonempty ^ 1u) & in_bounds);       // an empty transition is accepted iff the state is inside the bounds
-            const u64 im = (u64)((flg & 0xFu) | (1u << MA_MINE) | (acc_inc << MA_ACCEPTED) | ((hit ? 1u : 0u) << MA_REDO));
+            const u64 im = (u64)((flg & 0xFu) | (1u << MA_MINE) | (acc_inc << MA_ACCEPTED) | (hitw << MA_REDO));
             u32 inc = lane_in(im) ? 1u : 0u;
             inc = lane_in(1ull << MA_SUMK) ? ((flg >> 8) & 0xFFFu) : inc;
             // a count never goes below zero (reference assert, src/lib.rs:65; counts stay far below 2^63, so a negative sum is that)
