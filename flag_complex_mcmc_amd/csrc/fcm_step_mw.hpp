@@ -660,10 +660,14 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
     const u32 pidx = snap + (u32)lane;
     const u32 *e = ringL + (pidx & ring) * MW_REC_WORDS;                  // this lane's record (lanes >= nent: some record of the ring, masked below)
     const u32 a_head = mw_lds_addr(ctl), a_state = mw_lds_addr(e + SR_STATE);
-    u32 st;
+    u32 st, hv, hh;
+    auto doze = [&](u32 dist) {   // by how far off the token is (a decision takes several hundred cycles)
+        if (dist >= 4u) __builtin_amdgcn_s_sleep(MW_SLEEP_FAR);
+        else if (dist >= 2u) { if (MW_SLEEP_MID) __builtin_amdgcn_s_sleep(MW_SLEEP_MID); }
+        else if (MW_SPIN_NEAR == 0) __builtin_amdgcn_s_sleep(1);
+    };
     for (;;) {
         // head, then the state words -- one round trip, in this order: with head == q every state word read is final
-        u32 hv;
         asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(hv), "=&v"(st) : "v"(a_head), "v"(a_state) : "memory");
         const u32 h = mw_uni(hv);                                         // h <= q
         if (!hit && done != all) {
@@ -694,25 +698,25 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
                 else held = true;                                                   // only staged: it may yet be dropped -- wait
             }
         }
-        auto doze = [&](u32 dist) {   // by how far off the token is (a decision takes several hundred cycles)
-            if (dist >= 4u) __builtin_amdgcn_s_sleep(MW_SLEEP_FAR);
-            else if (dist >= 2u) { if (MW_SLEEP_MID) __builtin_amdgcn_s_sleep(MW_SLEEP_MID); }
-            else if (MW_SPIN_NEAR == 0) __builtin_amdgcn_s_sleep(1);
-        };
-        if (hit || done == all) {
-            // nothing left to check (the rule, long before the token arrives): a plain wait -- the path from the poll that
-            // finds head == q to the decision is what the chain's other waves wait for, instruction by instruction
-            u32 hh = h;
-#pragma nounroll
-            while (hh != q) {
-                doze(q - hh);
-                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(hv), "=&v"(st) : "v"(a_head), "v"(a_state) : "memory");
-                hh = mw_uni(hv);
-            }
-            break;
-        }
+        if (hit || done == all) { hh = h; break; }   // nothing left to check (the rule, long before the token arrives)
         if (h == q) continue;         // the token is here: the records that held the checks up are decided now
         doze(q - h);
+    }
+    // ... then a plain wait for the token.  The path from the poll that finds head == q to the decision is what the chain's
+    // other waves wait for, instruction by instruction: the wave next in line does nothing but read, compare and branch.
+#pragma nounroll
+    while (hh != q) {
+        if (MW_SPIN_NEAR && hh + 1u == q) {
+#pragma nounroll
+            do {
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(hv), "=&v"(st) : "v"(a_head), "v"(a_state) : "memory");
+                hh = mw_uni(hv);
+            } while (hh != q);
+            break;
+        }
+        doze(q - hh);
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(hv), "=&v"(st) : "v"(a_head), "v"(a_state) : "memory");
+        hh = mw_uni(hv);
     }
     __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
     if (hit) return 1u;
@@ -944,27 +948,35 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         // visible (vis, at its next proposal) every later proposal holds this decision against its reads anyway.
         MW_T(t_redo);
         const u32 eoff = (u32)min(lane, 8) * 32u;                              // this lane's count entry (lanes without one: entry 8)
-        const uint4 dyn = *(const uint4 *)((const char *)ent + eoff);          // count (x, y), flag (z)
-        const uint4 stat = *(const uint4 *)((const char *)ent + eoff + 16u);   // its bounds (the same round trip)
-        const u64 bmin = (u64)stat.x | ((u64)stat.y << 32), bmax = (u64)stat.z | ((u64)stat.w << 32);
-        const u64 cnt = (u64)dyn.x | ((u64)dyn.y << 32);
-        const u32 in_bounds = rdlane(dyn.z, 0);
+        const u32 ebase = mw_lds_addr(ent) + eoff;
+        // The entry's round trip is issued first; whatever does not depend on it -- flags, addresses, the state word less
+        // its commit bit, the new head -- is made ready while it is on its way (hipcc would wait first): a lone wave
+        // issues an instruction every ten cycles or so, and every one between the token and the head store is the chain's.
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u64 cnt; u32 flagw; u32x4 stat;                                        // count | inside-the-bounds flag | bmin, bmax
+        asm volatile("ds_read_b64 %0, %3\n\tds_read_b32 %1, %3 offset:8\n\tds_read_b128 %2, %3 offset:16"
+                     : "=&v"(cnt), "=&v"(flagw), "=&v"(stat) : "v"(ebase) : "memory");
         const u32 flg = rdlane(sv, SR_FLAGS);
-        const u32 nonempty = flg & SRF_NONEMPTY, is_dmove = (flg >> 1) & 1u;
-        const u64 ncnt = cnt + (u64)(long long)O.myd;
+        u32 nonempty = flg & SRF_NONEMPTY;
+        const u32 is_dmove = (flg >> 1) & 1u;
+        u64 md = (u64)(long long)O.myd;
+        static_assert(MS_REDONE == 8u && MS_ACCEPTED == 4u, "state word: flags by shifts");
+        u32 fin0 = (q << 4) | (hitw << 3) | MS_DECIDED;                        // the record's state word, less MS_ACCEPTED
+        u32 va_state = mw_lds_addr(stage + SR_STATE), va_head = mw_lds_addr(ctl), v_nh = q + 1u;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(md), "+s"(fin0), "+s"(nonempty), "+v"(va_state), "+v"(va_head), "+v"(v_nh), "+v"(cnt), "+v"(flagw), "+v"(stat) :: "memory");
+        const u64 bmin = (u64)stat.x | ((u64)stat.y << 32), bmax = (u64)stat.z | ((u64)stat.w << 32);
+        const u32 in_bounds = rdlane(flagw, 0);
+        const u64 ncnt = cnt + md;
         const u64 outside = ballot(ncnt < bmin) | ballot(ncnt > bmax);         // (two compares into SGPR pairs and a scalar OR)
         u32 commit;                                                            // = outside == 0 ? nonempty : 0, kept on the scalar side (hipcc goes through a VGPR and back)
         asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(commit) : "s"(outside), "s"(nonempty) : "scc");
         MW_T(t_dec1);
-        const u32 ebase = mw_lds_addr(ent) + eoff;
         if (commit) MW_LDS_ST64(ebase, ncnt, "0xff");
-        static_assert(MS_REDONE == 8u && MS_ACCEPTED == 4u, "state word: flags by shifts");
-        const u32 fin = (q << 4) | (hitw << 3) | (commit << 2) | MS_DECIDED;   // the record's state word
-        MW_LDS_ST32(mw_lds_addr(stage + SR_STATE), fin, "1");
+        const u32 fin = fin0 | (commit << 2);
+        MW_LDS_ST32(va_state, fin, "1");
         if (commit & (in_bounds ^ 1u)) { const u32 one = 1u; MW_LDS_ST32(ebase + 8u, one, "1"); }
         MW_T(t_dec2);
-        const u32 nh = q + 1u;
-        MW_LDS_ST32(mw_lds_addr(ctl), nh, "1");                                      // the token: after the entry and the counts, in order
+        MW_LDS_ST32(va_head, v_nh, "1");                                             // the token: after the entry and the counts, in order
         MW_T(t_head);
         MW_EV(4, 0);
 #ifdef MW_STAMP
