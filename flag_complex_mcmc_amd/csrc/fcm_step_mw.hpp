@@ -643,7 +643,7 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
     const u32 *ctl = (const u32 *)(smem + MW_HEAD_OFF);
     u64 *Hp = smem + MW_SHARED_WORDS + MW_RING_WORDS(W) + (size_t)wv * MW_WAVE_WORDS;
     u32 *tally = (u32 *)(smem + MW_TALLY_OFF);
-    bool held = false;
+    u64 heldm = 0ull;                                                     // (non-zero: waited for the decision of a staged record in conflict)
     const u32 cx0 = rdlane(sv, SR_CX0), cx1 = rdlane(sv, SR_CX1), dslot = rdlane(sv, SR_DSLOT);
     const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
     auto touches = [&](u32 ev) -> bool { return (rdlane(ev, SR_FLAGS) & SRF_NONEMPTY) ? mw_touches(ev, Lv1, Lv2, cx0, cx1, dslot, wid_clr, wid_set) : false; };
@@ -695,7 +695,7 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
                 if ((sti & (MS_DECIDED | MS_ACCEPTED)) == MS_DECIDED) { done |= 1ull << i; continue; }
                 if (!touches(ev)) done |= 1ull << i;
                 else if (sti & MS_DECIDED) hit = true;
-                else held = true;                                                   // only staged: it may yet be dropped -- wait
+                else heldm = 1ull;                                                  // only staged: it may yet be dropped -- wait
             }
         }
         if (hit || done == all) { hh = h; break; }   // nothing left to check (the rule, long before the token arrives)
@@ -704,6 +704,16 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
     }
     // ... then a plain wait for the token.  The path from the poll that finds head == q to the decision is what the chain's
     // other waves wait for, instruction by instruction: the wave next in line does nothing but read, compare and branch.
+    if (hit) {   // (to be run again under the token: its own, slower way out)
+#pragma nounroll
+        while (hh != q) {
+            doze(q - hh);
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(hv), "=&v"(st) : "v"(a_head), "v"(a_state) : "memory");
+            hh = mw_uni(hv);
+        }
+        __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);
+        return 1u;
+    }
 #pragma nounroll
     while (hh != q) {
         if (MW_SPIN_NEAR && hh + 1u == q) {
@@ -719,10 +729,9 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
         hh = mw_uni(hv);
     }
     __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);   // the chain's other waves are waiting for what follows: in front of the SIMD's other waves
-    if (hit) return 1u;
     // (st: read after head == q was -- final)
     u64 again = ballot((st & (MS_REDONE | MS_ACCEPTED)) == (MS_REDONE | MS_ACCEPTED)) & all;
-    if (again == 0ull && !held) return 0u;       // the rule: one scalar branch between the token and the decision
+    if ((again | heldm) == 0ull) return 0u;      // the rule: one scalar branch between the token and the decision
     if (again && lane == 0) atomicAdd(&tally[0], 1u);
     while (again && !hit) {
         const u32 i = (u32)__ffsll((long long)again) - 1u;
@@ -730,7 +739,7 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
         const u32 ev = lane < SR_WORDS ? ringL[((snap + i) & ring) * MW_REC_WORDS + lane] : 0u;
         hit = touches(ev);
     }
-    if (held && lane == 0) atomicAdd(&tally[1], 1u);
+    if (heldm && lane == 0) atomicAdd(&tally[1], 1u);
     return hit ? 1u : 0u;
 }
 
@@ -971,10 +980,11 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         u32 commit;                                                            // = outside == 0 ? nonempty : 0, kept on the scalar side (hipcc goes through a VGPR and back)
         asm("s_cmp_eq_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(commit) : "s"(outside), "s"(nonempty) : "scc");
         MW_T(t_dec1);
-        if (commit) MW_LDS_ST64(ebase, ncnt, "0xff");
+        // the counts, and with them -- second word of the entry, read from entry 0 only -- "the state is inside the bounds":
+        // after a commit it is (one store of two words, 8-byte aligned, instead of a test of the flag and a store of its own)
+        if (commit) { const u64 onew = 1ull; asm volatile("s_mov_b64 exec, 0xff\n\tds_write2_b64 %0, %1, %2 offset1:1\n\ts_mov_b64 exec, -1" :: "v"(ebase), "v"(ncnt), "v"(onew) : "memory"); }
         const u32 fin = fin0 | (commit << 2);
         MW_LDS_ST32(va_state, fin, "1");
-        if (commit & (in_bounds ^ 1u)) { const u32 one = 1u; MW_LDS_ST32(ebase + 8u, one, "1"); }
         MW_T(t_dec2);
         MW_LDS_ST32(va_head, v_nh, "1");                                             // the token: after the entry and the counts, in order
         MW_T(t_head);
