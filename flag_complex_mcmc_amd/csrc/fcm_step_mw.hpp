@@ -712,6 +712,7 @@ __device__ __attribute__((noinline)) u32 mw_wait_staged(u64 *smem, u32 wv, u32 q
             hh = mw_uni(hv);
         }
         __builtin_amdgcn_s_setprio(MW_PRIO_TOKEN);
+        if (heldm && lane == 0) atomicAdd(&tally[1], 1u);
         return 1u;
     }
 #pragma nounroll
