@@ -152,16 +152,18 @@ def load_traffic(config, n_chains, proposals, moves, this_lib, sparse=None):
         recs = json.load(open(path))
     except Exception:
         return None, None
+    stale = None
     for rec in (recs if isinstance(recs, list) else [recs]):
         if rec.get("config", 2) == config and rec.get("n_chains") == n_chains and rec.get("moves", "simple") == moves:
             if sparse is not None and bool(rec.get("sparse_state", False)) != bool(sparse):
                 continue            # (the record is of the other state layout: FCM_SPARSE)
-            if rec.get("lib_sha16") != this_lib:
-                return None, "STALE: profiled build %s != this build %s (profiles/pmc_summary.json, %s)" % (rec.get("lib_sha16"), this_lib, rec.get("tag", "?"))
+            if rec.get("lib_sha16") != this_lib:   # (a later record of the same command may be of this build: keep looking)
+                stale = stale or "STALE: profiled build %s != this build %s (profiles/pmc_summary.json, %s)" % (rec.get("lib_sha16"), this_lib, rec.get("tag", "?"))
+                continue
             scale = float(proposals) / float(rec.get("proposals") or proposals)
-            return rec.get("hbm_bytes_per_launch") * scale, ("replayed from profiles/pmc_summary.json (%s, build %s%s): rocprofv3 --pmc passes of this command, not this run"
+            return rec.get("hbm_bytes_per_launch") * scale, ("fabric-side fetch + write-back (Infinity Cache + HBM) by FETCH_SIZE / WRITE_SIZE, replayed from profiles/pmc_summary.json (%s, build %s%s): rocprofv3 --pmc passes of this command, not this run"
                                                              % (rec.get("tag", "?"), this_lib, "" if scale == 1.0 else ", scaled x%g from %d proposals per launch" % (scale, rec.get("proposals"))))
-    return None, None
+    return None, stale
 
 
 def log(msg):
@@ -323,10 +325,11 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- parity gate on this rank's result (outside the timed region) ----------
-    keys = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big", "n_recheck", "n_held")
+    keys = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big", "n_recheck", "n_held", "n_pairs", "n_shared_rows")
+    probe = bool(os.environ.get("FCM_BENCH_PROBE"))   # instruction-cost probe builds (wrong results by design): no parity gate, and the line says so
     d = {k: (st1[k].astype(np.int64) - st0[k].astype(np.int64)).sum() for k in keys}
     assert d["sampled"] == (hi - lo) * args.steps * args.proposals, "proposal count mismatch"
-    assert os.environ.get("FCM_BENCH_PROBE") or (st1["status"] == 0).all(), "device-side consistency check failed"
+    assert probe or (st1["status"] == 0).all(), "device-side consistency check failed"
 
     def strip(v):  # flag_count never shrinks in length (src/lib.rs:72-74): ignore trailing zeros
         v = list(v)
@@ -334,7 +337,7 @@ def main():
             v.pop()
         return v
 
-    for c in (() if os.environ.get("FCM_BENCH_PROBE") else (0, (hi - lo) // 2, hi - lo - 1)):   # (FCM_BENCH_PROBE: instruction-cost probe builds, wrong results by design)
+    for c in (() if probe else (0, (hi - lo) // 2, hi - lo - 1)):
         assert s.graph(c).flagser_count(local_rank) == strip(s.flag_count(c)), "incremental counts != full recount (chain %d)" % c
         assert bounds.check(s.flag_count(c)), "chain %d left the bounds" % c
     # the gathered matrix holds every rank's chains, in global chain order
@@ -348,8 +351,8 @@ def main():
         long_rows = n > 1024
         sparse = bool(s.info.get("sparse_state", 0))
         clique = weights[2] > 0 or weights[3] > 0
-        # clique moves: rows that are read once are charged once (a sampler with clique moves counts pairs and shared rows in slots 14, 15)
-        clique_bytes = algorithmic_bytes(d, n, (float(d["n_recheck"]), float(d["n_held"]))) / args.steps if clique else None
+        # clique moves: rows that are read once are charged once (FCM_STAT_PAIRS, FCM_STAT_SHARED_ROWS)
+        clique_bytes = algorithmic_bytes(d, n, (float(d["n_pairs"]), float(d["n_shared_rows"]))) / args.steps if clique else None
         abytes = sparse_bytes(d, mean_k) / args.steps if sparse else (needed_bytes(d, n, mean_k) / args.steps if long_rows else (clique_bytes if clique else survey_bytes))
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         this_lib = lib_sha16(fcm.LIB_PATH)
@@ -372,9 +375,11 @@ def main():
             "clique_move_fraction": float(d["n_cperm"] + d["n_cswap"]) / float(d["sampled"]),
             "changed_edges_per_clique_move": float(d["n_changes"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"])),
             "rare_paths_per_1e6": {k: 1e6 * float(d[k]) / float(d["sampled"]) for k in (("n_redo", "n_wide", "n_big") + (() if clique else ("n_recheck", "n_held")))},
-            **({"changed_pairs_per_clique_move": float(d["n_recheck"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"]))} if clique else {}),
+            **({"changed_pairs_per_clique_move": float(d["n_pairs"]) / max(1.0, float(d["n_cperm"] + d["n_cswap"]))} if clique else {}),
             "count_histogram_dim2_distinct": int(len(fdist.count_histogram(all_counts, 2)[0])),
-            "parity": "counts == full GPU recount on 3 chains; oracle parity in tests/ -m gpu",
+            "parity": ("NOT CHECKED: FCM_BENCH_PROBE run (probe build, results wrong by design)" if probe
+                       else "counts == full GPU recount on 3 chains; oracle parity in tests/ -m gpu"),
+            **({"probe": True} if probe else {}),
             "gathered_chains": int(all_counts.shape[0]),
             "collective": {"backend": backend, "world_size_seen": dist.get_world_size() if world > 1 else 1,
                            "what": "all_gather of per-chain count vectors + counters, inside the timed region"},
@@ -390,12 +395,15 @@ def main():
                          "survey_bytes_per_launch": survey_bytes,
                          **({"sector_model_bytes_per_launch": sparse_sector_bytes(d, mean_k) / args.steps,
                              "traffic_over_sector_model": (traffic / (sparse_sector_bytes(d, mean_k) / args.steps)) if traffic else None} if sparse else {}),
-                         "kernel": ("fcm_step_cq_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel") if (weights[2] > 0 or weights[3] > 0)
+                         "kernel": ("fcm_step_cq_kernel" if s.info["cooperative_clique_kernel"] else "fcm_step_kernel") if clique
                                    else ("fcm_step_mw_kernel" if s.info["waves_per_chain"] >= 2 else "fcm_step_kernel"),
                          "waves_per_chain": int(s.info["waves_per_chain"])},
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == 2 and args.moves == "simple":
-            out["cpu_baseline"] = cpu_baseline(n, edges, (bounds.flag_count_min, bounds.flag_count_max), args.seed)
+        # the reference-faithful CPU port beside it, in the same run, on rank 0's host cores, whatever the number of ranks
+        # (outside the timed region; north_star: "next to the reference Rust CPU path timed on the box's host cores")
+        if not args.no_cpu_baseline and args.config == 2 and args.moves == "simple":
+            out["cpu_baseline"] = cpu_baseline(n, edges, (bounds.flag_count_min, bounds.flag_count_max), args.seed,
+                                               target_seconds=float(os.environ.get("FCM_BENCH_CPU_SECONDS", "15")))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

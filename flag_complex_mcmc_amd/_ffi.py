@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FCM_LIB_PATH") or os.path.join(_HERE, "libfcm.so")
 
 MAX_COUNTS = 16
-NSTATS = 16
+NSTATS = 18
 STAT_NAMES = ("sampled", "accepted", "n_empty", "n_flip", "n_dmove", "sum_k", "count_len", "status",
-              "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big", "n_recheck", "n_held")
+              "n_cperm", "n_cswap", "n_changes", "n_redo", "n_wide", "n_big", "n_recheck", "n_held", "n_pairs", "n_shared_rows")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_PANIC, ERR_NOMEM, ERR_INTERNAL = range(9)
 
@@ -47,7 +47,12 @@ class CSamplerInfo(C.Structure):
                 ("n_double", C.c_uint64), ("k_max", C.c_uint32), ("k_mean", C.c_double),
                 ("bytes_per_chain", C.c_uint64), ("bytes_static", C.c_uint64),
                 ("ncounts", C.c_int32), ("lossless", C.c_int32), ("n_chains", C.c_uint32), ("waves_per_chain", C.c_uint32),
-                ("sparse_state", C.c_uint32)]
+                ("sparse_state", C.c_uint32), ("cooperative_clique_kernel", C.c_uint32)]
+
+
+class CStateInfo(C.Structure):
+    _fields_ = [("sample_number", C.c_uint64), ("total_chains", C.c_uint64), ("set_id", C.c_uint64), ("seed", C.c_uint64),
+                ("n", C.c_uint32), ("n_chains", C.c_uint32), ("first_chain_id", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/fcm.h declares
@@ -98,6 +103,8 @@ SIGNATURES = {
     "fcm_sampler_single_edge_flip": (C.c_int, [vp, C.c_uint32, C.c_uint64, u32p, i32p, C.POINTER(C.c_uint32)]),
     "fcm_sampler_save_state": (C.c_int, [vp, C.c_char_p, C.c_uint64]),
     "fcm_sampler_load_state": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp), u64p]),
+    "fcm_sampler_save_state_shard": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "fcm_state_file_info": (C.c_int, [C.c_char_p, C.POINTER(CStateInfo)]),
 }
 
 _lib = None

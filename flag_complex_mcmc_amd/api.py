@@ -274,11 +274,9 @@ class MCMCSampler:
     def stats(self):
         out = np.zeros((self.n_chains, _ffi.NSTATS), np.uint64)
         check(lib().fcm_sampler_get_stats(self._h, out.ctypes.data_as(u64p)))
-        d = {name: out[:, i].copy() for i, name in enumerate(_ffi.STAT_NAMES)}
-        # slots 14 and 15 under the names they have on a sampler with clique moves (include/fcm.h: FCM_STAT_PAIRS,
-        # FCM_STAT_SHARED_ROWS); on a simple-move sampler they are n_recheck and n_held
-        d["n_pairs"], d["n_shared_rows"] = d["n_recheck"], d["n_held"]
-        return d
+        # (every slot has one meaning on every sampler, include/fcm.h FCM_STAT_*: n_recheck / n_held stay 0 on a sampler
+        # with clique moves, n_pairs / n_shared_rows on a simple-move one)
+        return {name: out[:, i].copy() for i, name in enumerate(_ffi.STAT_NAMES)}
 
     @property
     def sampled(self):
@@ -437,6 +435,67 @@ class MultiDeviceSampler:
     def next(self):
         self._parallel(lambda r: self.shards[r].next())
         return self
+
+    @staticmethod
+    def shard_file(fname, r, n_shards):
+        """<fname> for a single shard (the single-device layout), <fname>.shard<r> otherwise."""
+        return fname if n_shards == 1 else "%s.shard%d" % (fname, r)
+
+    def save_state(self, fname, sample_number=0):
+        """One state file per shard, each carrying its place in the set (fcm_sampler_save_state_shard): all of them are
+        written to <file>.new first and moved into place once every one is complete."""
+        import time
+        G = len(self.shards)
+        set_id = ((sample_number << 32) ^ int(time.time()) ^ (os.getpid() << 20)) & 0xFFFFFFFFFFFFFFFF
+        self._parallel(lambda r: check(lib().fcm_sampler_save_state_shard(
+            self.shards[r]._h, os.fsencode(self.shard_file(fname, r, G) + ".new"), sample_number, r, G, self.n_chains, set_id)))
+        for r in range(G):
+            os.replace(self.shard_file(fname, r, G) + ".new", self.shard_file(fname, r, G))
+
+    @staticmethod
+    def state_file_info(fname):
+        info = _ffi.CStateInfo()
+        check(lib().fcm_state_file_info(os.fsencode(fname), C.byref(info)))
+        return {f: int(getattr(info, f)) for f, _ in _ffi.CStateInfo._fields_}
+
+    @classmethod
+    def load_state(cls, fname, devices):
+        """-> (sample_number, sampler).  The number of shards comes from the files: shard r goes to devices[r % len(devices)]
+        (a state saved on 4 handles resumes on 2 devices or on 1).  Raises if a shard is missing, if the files are not of
+        one save, or if their chain ranges do not tile 0 .. total-1."""
+        if not devices:
+            raise FcmError(_ffi.ERR_INVALID, "no devices")
+        sharded = os.path.exists(fname + ".shard0")
+        if sharded and os.path.exists(fname):   # both layouts on disk: the newer save
+            one, many = cls.state_file_info(fname), cls.state_file_info(fname + ".shard0")
+            first = many if many["sample_number"] >= one["sample_number"] else one
+        else:
+            first = cls.state_file_info(fname + ".shard0" if sharded else fname)
+        G = first["shard_count"]
+        at = first["first_chain_id"] if first["shard_index"] == 0 else 0   # (a single handle's file may start at any global chain id)
+        for r in range(G):
+            f = cls.shard_file(fname, r, G)
+            if not os.path.exists(f):
+                raise FcmError(_ffi.ERR_IO, "%s: shard %d of %d is missing" % (f, r, G))
+            h = cls.state_file_info(f)
+            if h["shard_index"] != r or any(h[k] != first[k] for k in ("shard_count", "total_chains", "set_id", "sample_number", "seed", "n")):
+                raise FcmError(_ffi.ERR_IO, "%s: not a shard of the same save as %s" % (f, cls.shard_file(fname, 0, G)))
+            if h["first_chain_id"] != at:
+                raise FcmError(_ffi.ERR_IO, "%s: its chains start at %d, the shards before it end at %d" % (f, h["first_chain_id"], at))
+            at += h["n_chains"]
+        if at != first["total_chains"]:
+            raise FcmError(_ffi.ERR_IO, "%s: the shards hold %d chains, the run had %d" % (fname, at, first["total_chains"]))
+        self = cls.__new__(cls)
+        self.devices = [devices[r % len(devices)] for r in range(G)]
+        self.ranges = [None] * G
+        self.shards = self._parallel(lambda r: MCMCSampler.load_state(cls.shard_file(fname, r, G), self.devices[r])[1])
+        self.ranges, lo = [], 0
+        for s in self.shards:
+            self.ranges.append((lo, lo + s.n_chains))
+            lo += s.n_chains
+        self.n_chains = lo
+        self.bounds = None
+        return first["sample_number"], self
 
     def flag_counts(self):
         return np.concatenate(self._parallel(lambda r: self.shards[r].flag_counts()), axis=0)

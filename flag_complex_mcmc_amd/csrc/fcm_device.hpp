@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 #define FCM_DEV_MAX_COUNTS 16
-#define FCM_DEV_NSTATS 16
+#define FCM_DEV_NSTATS 18
 #define FCM_MAX_SUB 32           // philox blocks (2 candidates each) tried for the single edge of a double-edge move
 #define FCM_LAUNCH_CHUNK (1u << 16)  // proposals per chain per kernel launch
 
@@ -19,7 +19,7 @@ struct FcmEdgeEntry {
 //   rows  [n_chains][n][stride32] u32   out-row bitmaps, one chain after another; row = 128-B multiple
 //   dbl   [n_chains][dbl_stride]  u32   reciprocal-pair slot list (undirected edge ids)
 //   counts[n_chains][16]          u64   flag_count per chain
-//   stats [n_chains][16]          u64   FCM_STAT_* counters
+//   stats [n_chains][18]          u64   FCM_STAT_* counters
 struct FcmStepParams {
     const FcmEdgeEntry *etab;  // [U]
     const uint32_t *nb;        // concatenated neighbour lists
@@ -54,6 +54,8 @@ struct FcmStepParams {
     uint64_t guard_limit;      // largest local count bound a walk may reach before it refuses (2^31 - 1; fcm_count_guard)
     uint32_t mw_waves;         // multi-wave kernel (fcm_step_mw.hpp): waves per chain, a power of two 2..16; 0 = one-wave kernel
                                // (the cooperative clique-move kernel, fcm_step_cq.hpp: its waves per chain, 0 = 1)
+    uint32_t commit_words;     // u32 words of one chain's mutable record (= rows_per_chain): the multi-wave and cooperative kernels hold a commit's
+                               // word indices against it before they store (test hook FCM_TEST_COMMIT_LIMIT lowers it)
     uint32_t sparse;           // 1: `rows` holds, per chain, two bits per adjacent pair (rows_per_chain u32 words) instead of row bitmaps, and `nb`
                                // the local pair ids behind every neighbour list (fcm_step_mw.hpp, mw_build_sparse); multi-wave kernel only
 };

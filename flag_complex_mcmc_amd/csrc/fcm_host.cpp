@@ -923,6 +923,8 @@ try {
         s->bits_stride = (s->bits_stride + 31u) / 32u * 32u;
     }
     const uint64_t rows_per_chain = s->sparse ? (uint64_t)s->bits_stride : (uint64_t)g->n * g->stride32;
+    if (rows_per_chain * 4ull >= (1ull << 32))   // (the kernels address a chain's record through a buffer descriptor with 32-bit offsets)
+        return fail(FCM_ERR_UNSUPPORTED, "a chain's bitmap would take %llu bytes; this build addresses at most 4 GiB per chain", (unsigned long long)(rows_per_chain * 4ull));
     const uint32_t dbl_stride = (uint32_t)((D + 31) / 32 * 32);
     const uint32_t C = cfg->n_chains;
     if ((rc = s->d_etab.alloc(std::max<size_t>(1, etab.size()) * sizeof(FcmEdgeEntry)))) return rc;
@@ -1076,6 +1078,8 @@ try {
     p.sparse = s->sparse ? 1u : 0u;
     p.guard_limit = 0x7FFFFFFFull;
     if (const char *e = getenv("FCM_TEST_GUARD_LIMIT")) p.guard_limit = strtoull(e, nullptr, 10);   // test hook (tests/test_gpu_parity.py)
+    p.commit_words = (uint32_t)rows_per_chain;
+    if (const char *e = getenv("FCM_TEST_COMMIT_LIMIT")) p.commit_words = (uint32_t)strtoul(e, nullptr, 10);   // test hook: a commit's word index at or beyond it is "out of range"
 
     if (s->cfg.sample_distance == 0) s->cfg.sample_distance = fcm_default_sample_distance(fc[1]);  // sample.rs:102
 
@@ -1128,6 +1132,7 @@ try {
             I.waves_per_chain = Wc;
             p.mw_waves = Wc >= 2 ? Wc : 0u;
         }
+        I.cooperative_clique_kernel = s->use_cq ? 1u : 0u;
     }
 
     guard.s = nullptr;
@@ -1684,14 +1689,19 @@ try {
 // ---------------------------------------------------------------------------
 // Checkpoint / resume (role of src/io.rs:51-62)
 // ---------------------------------------------------------------------------
-static const char FCM_STATE_MAGIC[8] = {'F', 'C', 'M', 'S', 'T', 'A', 'T', '3'};
+static const char FCM_STATE_MAGIC[8] = {'F', 'C', 'M', 'S', 'T', 'A', 'T', '4'};
 
 struct StateHeader {
     char magic[8];
     uint64_t sample_number;
     uint32_t n, n_chains;
     uint64_t U, D;
-    int32_t ncounts, reserved;
+    int32_t ncounts, nstats;
+    // the set this file belongs to when the chains of a run are saved as one file per handle (fcm_sampler_save_state_shard):
+    // which shard of how many, the chains of the whole run and a number every file of one save carries (cfg.first_chain_id
+    // says where this shard's chains sit).  A single-handle save is shard 0 of 1.
+    uint32_t shard_index, shard_count;
+    uint64_t total_chains, set_id;
     fcm_sampler_config cfg;
     fcm_bounds bounds;
 };
@@ -1700,8 +1710,17 @@ template <class T> static bool wr(FILE *f, const T *p, size_t cnt) { return cnt 
 template <class T> static bool rd(FILE *f, T *p, size_t cnt) { return cnt == 0 || fread(p, sizeof(T), cnt, f) == cnt; }
 
 extern "C" int fcm_sampler_save_state(fcm_sampler *s, const char *path, uint64_t sample_number)
+{
+    return fcm_sampler_save_state_shard(s, path, sample_number, 0u, 1u, s ? (uint64_t)s->cfg.first_chain_id + s->params.nchains : 0u, 0u);   // (a set of one: chains first_chain_id .. of a run that ends there)
+}
+
+extern "C" int fcm_sampler_save_state_shard(fcm_sampler *s, const char *path, uint64_t sample_number, uint32_t shard_index, uint32_t shard_count,
+                                            uint64_t total_chains, uint64_t set_id)
 try {
     if (!s || !path) return fail(FCM_ERR_INVALID, "NULL argument");
+    if (shard_count == 0 || shard_index >= shard_count || (uint64_t)s->cfg.first_chain_id + s->params.nchains > total_chains)
+        return fail(FCM_ERR_INVALID, "shard %u of %u holding chains %u..%llu of %llu: not a shard of that run", shard_index, shard_count, s->cfg.first_chain_id,
+                    (unsigned long long)s->cfg.first_chain_id + s->params.nchains, (unsigned long long)total_chains);
     std::vector<uint64_t> hs;
     int rc = fetch_stats(s, hs);   // syncs; refuses to save a chain whose device-side checks failed
     if (rc) return rc;
@@ -1715,7 +1734,8 @@ try {
     memset(&h, 0, sizeof h);
     memcpy(h.magic, FCM_STATE_MAGIC, 8);
     h.sample_number = sample_number;
-    h.n = s->n; h.n_chains = C; h.U = U; h.D = D; h.ncounts = s->params.ncounts;
+    h.n = s->n; h.n_chains = C; h.U = U; h.D = D; h.ncounts = s->params.ncounts; h.nstats = FCM_NSTATS;
+    h.shard_index = shard_index; h.shard_count = shard_count; h.total_chains = total_chains; h.set_id = set_id;
     h.cfg = s->cfg; h.bounds = s->bounds;
     bool ok = wr(f, &h, 1) && wr(f, s->ue.data(), s->ue.size());
     std::vector<uint64_t> hc((size_t)C * FCM_MAX_COUNTS);
@@ -1743,7 +1763,9 @@ try {
     struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{f};
     StateHeader h;
     if (!rd(f, &h, 1) || memcmp(h.magic, FCM_STATE_MAGIC, 8) != 0) return fail(FCM_ERR_IO, "%s is not a libfcm state file", path);
-    if (h.n_chains == 0 || h.ncounts < 2 || h.ncounts > FCM_MAX_COUNTS) return fail(FCM_ERR_IO, "%s: corrupt header", path);
+    if (h.n_chains == 0 || h.ncounts < 2 || h.ncounts > FCM_MAX_COUNTS || h.nstats != FCM_NSTATS || h.shard_count == 0 || h.shard_index >= h.shard_count
+        || (uint64_t)h.cfg.first_chain_id + h.n_chains > h.total_chains || h.cfg.n_chains != h.n_chains)
+        return fail(FCM_ERR_IO, "%s: corrupt header", path);
     // Every size below comes from the file: hold the header against the graph it claims and against the
     // file's length before anything is allocated from it.
     const uint64_t U = h.U, D = h.D;
@@ -1832,6 +1854,23 @@ try {
     return FCM_OK;
 } FCM_CATCH
 
+
+// The header of a state file, without loading it: what a caller that saved one file per handle needs to put the set back together.
+extern "C" int fcm_state_file_info(const char *path, fcm_state_info *out)
+try {
+    if (!path || !out) return fail(FCM_ERR_INVALID, "NULL argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(FCM_ERR_IO, "unable to load state %s", path);
+    StateHeader h;
+    const bool ok = rd(f, &h, 1);
+    fclose(f);
+    if (!ok || memcmp(h.magic, FCM_STATE_MAGIC, 8) != 0) return fail(FCM_ERR_IO, "%s is not a libfcm state file", path);
+    if (h.n_chains == 0 || h.shard_count == 0 || h.shard_index >= h.shard_count || (uint64_t)h.cfg.first_chain_id + h.n_chains > h.total_chains)
+        return fail(FCM_ERR_IO, "%s: corrupt header", path);
+    out->sample_number = h.sample_number; out->total_chains = h.total_chains; out->set_id = h.set_id; out->seed = h.cfg.seed;
+    out->n = h.n; out->n_chains = h.n_chains; out->first_chain_id = h.cfg.first_chain_id; out->shard_index = h.shard_index; out->shard_count = h.shard_count;
+    return FCM_OK;
+} FCM_CATCH
 
 // Diagnostic: the per-chain cycle sums a -DFCM_STAMP build accumulates (zeros in the product build).
 extern "C" int fcm_sampler_debug_stamps(fcm_sampler *s, uint64_t *out /* [n_chains][8] */)

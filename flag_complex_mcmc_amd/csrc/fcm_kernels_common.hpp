@@ -390,6 +390,12 @@ __device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, in
 #ifndef FCM_SEAT_BRANCHY
 #define FCM_SEAT_BRANCHY 0   // 1: pick 32-bit halves by scalar branches (fewer VALU, more SALU and branches)
 #endif
+#ifndef FCM_SEAT_VEC
+#define FCM_SEAT_VEC 8       // extras up to which the seating runs as vector code (beyond: the wave-uniform loops)
+#endif
+#ifndef FCM_EVAL_V2
+#define FCM_EVAL_V2 1        // round 4: the evaluator's scalar-heavy parts as vector code (the CU's one scalar unit is what this kernel family saturates first)
+#endif
 
 struct Cls { u64 P, M, S; };
 
@@ -432,8 +438,11 @@ __device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sig
 {
     if constexpr (T < MAXT) {
         if (T + 1 <= tmax) {
-            delta[T + 1] += sign * __popcll(cand);
-            if (DETECT || T + 2 <= tmax) {
+            const int pc = __popcll(cand);
+            delta[T + 1] += sign * pc;
+            // (a lone child has no children inside `cand` -- a row never holds its own node -- so a node with one child is a
+            //  leaf: its lane sits the loop out.  Lockstep: the wave runs max-over-lanes trips, and most lanes have one child)
+            if (DETECT || (T + 2 <= tmax && (!FCM_EVAL_V2 || pc > 1))) {
                 u64 c = cand;
                 while (c) {
                     const int x = __ffsll((long long)c) - 1;
@@ -580,6 +589,47 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
     u64 N1 = prim1, N2 = prim2;
     // raw out-mask of the vertex this lane's node stands for, as two halves
     u32 blo = (u32)myH & ~(u32)uv, bhi = (u32)(myH >> 32) & ~(u32)(uv >> 32);
+    const u64 gprim = c.P | prim1 | prim2;
+    u32 rlo, rhi;
+#if FCM_EVAL_V2
+    // The extras as vector code.  Extra r (the vertices of xm ascending, then those of xs) is node k + r.  With up to
+    // FCM_SEAT_VEC extras -- two on average on the headline graph -- the lanes do all of it among themselves through a few
+    // words of LDS (the arc list's place, free until the scatter): an extra's lane leaves its raw mask and its own index at its
+    // rank (v_mbcnt), the seat's lane picks the mask up, and every lane moves, for each extra, bit `orig` of its mask to bit
+    // k + r of its row by a per-lane shift.  No wave-uniform loop, two exec-masked stores: the scalar loops this replaces
+    // cost 18 scalar instructions per extra (tools/bb_census.py), on the CU's one scalar unit.
+    const u64 xa = xm | xs;
+    const int nm = __popcll(xm), ne = nm + __popcll(xs);
+    if (xa != 0ull && ne <= FCM_SEAT_VEC) {
+        u64 *seatbuf = Hp + WAVE;
+        unsigned char *olist = (unsigned char *)(seatbuf + 56);
+        const u32 rkm = __builtin_amdgcn_mbcnt_hi((u32)(xm >> 32), __builtin_amdgcn_mbcnt_lo((u32)xm, 0u));
+        const u32 rks = __builtin_amdgcn_mbcnt_hi((u32)(xs >> 32), __builtin_amdgcn_mbcnt_lo((u32)xs, (u32)nm));
+        const u64 braw = (u64)blo | ((u64)bhi << 32);
+        if (lane_in(xm)) { seatbuf[rkm] = braw; olist[rkm] = (unsigned char)lane; }
+        if (lane_in(xs)) { seatbuf[rks] = braw; olist[rks] = (unsigned char)lane; }
+        wave_sync();
+        const u32 rs = (u32)lane - (u32)k;                        // this lane's seat number, if it is one
+        const u64 got = seatbuf[min(rs, 55u)];
+        const u32 w0 = *(const u32 *)olist;                        // (wave-uniform address: the indices of extras 0..3, a byte each)
+        const bool seat = rs < (u32)ne;
+        blo = seat ? (u32)got : blo; bhi = seat ? (u32)(got >> 32) : bhi;
+        const u64 em = ((1ull << nm) - 1ull) << k, ea = ((1ull << ne) - 1ull) << k;
+        N1 |= em; N2 |= ea & ~em;
+        const u64 b64 = (u64)blo | ((u64)bhi << 32);
+        u32 eb = (u32)((b64 >> (w0 & 63u)) & 1ull) | ((u32)((b64 >> ((w0 >> 8) & 63u)) & 1ull) << 1);
+        if (ne > 2) eb |= ((u32)((b64 >> ((w0 >> 16) & 63u)) & 1ull) << 2) | ((u32)((b64 >> ((w0 >> 24) & 63u)) & 1ull) << 3);
+        if (ne > 4) {
+            const u32 w1 = *(const u32 *)(olist + 4);
+            eb |= ((u32)((b64 >> (w1 & 63u)) & 1ull) << 4) | ((u32)((b64 >> ((w1 >> 8) & 63u)) & 1ull) << 5);
+            if (ne > 6) eb |= ((u32)((b64 >> ((w1 >> 16) & 63u)) & 1ull) << 6) | ((u32)((b64 >> ((w1 >> 24) & 63u)) & 1ull) << 7);
+        }
+        eb &= (1u << ne) - 1u;                                     // (slots beyond the last extra hold whatever an earlier evaluation left)
+        const u64 es64 = (u64)eb << k;
+        rlo = (blo & (u32)gprim) | (u32)es64; rhi = (bhi & (u32)(gprim >> 32)) | (u32)(es64 >> 32);
+        wave_sync();
+    } else {
+#endif
     // pass 1: seat the extra nodes (wave-uniform loops, a handful of trips): the seat's lane takes the vertex's mask
     int r = 0;
     for (u64 m = xm; m; m &= m - 1, ++r) {
@@ -598,16 +648,34 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
     }
     // pass 2: a child vertex shows up at its own index and at each of its extras (bit `orig` of the mask goes to bit `pos`;
     // both wave-uniform, so the half words involved are picked by scalar branches)
-    const u64 gprim = c.P | prim1 | prim2;
-    u32 rlo = blo & (u32)gprim, rhi = bhi & (u32)(gprim >> 32);
+    rlo = blo & (u32)gprim; rhi = bhi & (u32)(gprim >> 32);
     r = 0;
     for (u64 m = xm; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, r < 2 ? k + r : s + r - 2);
     for (u64 m = xs; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, r < 2 ? k + r : s + r - 2);
-    // children must not come earlier in the P*M*S* order
-    const u64 G2 = N2, G1 = N1 | N2, G0 = c.P | G1;
-    const bool inP = lane_in(c.P), in1 = lane_in(N1), in2 = lane_in(N2);
-    rlo &= inP ? (u32)G0 : (in1 ? (u32)G1 : (in2 ? (u32)G2 : 0u));
-    rhi &= inP ? (u32)(G0 >> 32) : (in1 ? (u32)(G1 >> 32) : (in2 ? (u32)(G2 >> 32) : 0u));
+#if FCM_EVAL_V2
+    }
+#endif
+    // children must not come earlier in the P*M*S* order: a P node may have any node as a child (G0), an M node the M and S
+    // nodes (G1), an S node S nodes (G2), a lane that is no node nothing.  G0 > G1 > G2, so allowed = G2 | N1 & [P or M
+    // node] | P & [P node], cut to the node lanes -- as lane masks turned into all-ones words and plain vector ANDs / ORs (no
+    // branches: hipcc makes nested selects on SGPR-pair conditions into exec-mask regions, 25 scalar instructions and six branches)
+    const u64 G1 = N1 | N2, G0 = c.P | G1;
+#if FCM_EVAL_V2
+    {
+        const u32 selP = lane_in(c.P) ? 0xFFFFFFFFu : 0u, selPM = lane_in(c.P | N1) ? 0xFFFFFFFFu : 0u, selN = lane_in(G0) ? 0xFFFFFFFFu : 0u;
+        u32 alo = selPM & (u32)N1, ahi = selPM & (u32)(N1 >> 32);
+        alo |= selP & (u32)c.P; ahi |= selP & (u32)(c.P >> 32);
+        alo |= (u32)N2; ahi |= (u32)(N2 >> 32);
+        rlo &= alo & selN; rhi &= ahi & selN;
+    }
+#else
+    {
+        const u64 G2 = N2;
+        const bool inP = lane_in(c.P), in1 = lane_in(N1), in2 = lane_in(N2);
+        rlo &= inP ? (u32)G0 : (in1 ? (u32)G1 : (in2 ? (u32)G2 : 0u));
+        rhi &= inP ? (u32)(G0 >> 32) : (in1 ? (u32)(G1 >> 32) : (in2 ? (u32)(G2 >> 32) : 0u));
+    }
+#endif
     Hp[lane] = (u64)rlo | ((u64)rhi << 32);
     wave_sync();
     FCM_STAMP_PTR(3);                                                  // (flips-only diagnostic) classes, seating, split rows
@@ -694,6 +762,9 @@ __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u
 // local vertex list of an adjacent pair: K, then big, small
 __device__ __forceinline__ u32 load_list(const u32 *nb, u32 off, int k, u32 big, u32 small, int lane)
 {
+#if defined(MW_ABL) && (MW_ABL & 32)   // (ablation probe: no list loads -- made-up vertices)
+    return lane < k ? (((u32)lane + 1u) * 40503u + big * 7u + off) % 997u : (lane == k ? big : small);
+#endif
     return lane < k ? nb[off + lane] : (lane == k ? big : small);
 }
 
@@ -1406,7 +1477,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         st_g[4] += rdlane(tl, OT_DMOVE); st_g[5] += rdlane(tl, OT_SUMK); if (nlen > st_g[6]) st_g[6] = nlen; st_g[7] |= stw;
         st_g[8] += rdlane(tl, OT_CPERM); st_g[9] += rdlane(tl, OT_CSWAP); st_g[10] += rdlane(tl, OT_CHANGES);
         st_g[12] += rdlane(tl, OT_WIDE); st_g[13] += rdlane(tl, OT_BIG);
-        if constexpr (CLIQUE != 0) { st_g[14] += rdlane(tl, OT_PAIRS); st_g[15] += rdlane(tl, OT_SHARED); }   // (a simple-move sampler: the multi-wave kernel's n_recheck, n_held)
+        if constexpr (CLIQUE != 0) { st_g[16] += rdlane(tl, OT_PAIRS); st_g[17] += rdlane(tl, OT_SHARED); }   // (FCM_STAT_PAIRS, FCM_STAT_SHARED_ROWS: slots of their own)
 #ifdef FCM_STAMP
         for (int q = 0; q < 8; ++q) p.dbgbuf[(size_t)chain * 8 + q] += stamp_acc[q];
 #endif

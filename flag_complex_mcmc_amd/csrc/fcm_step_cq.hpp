@@ -383,6 +383,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
             *(u64 *)(ctx + MC_CUM0) = p.cum0; *(u64 *)(ctx + MC_CUM1) = p.cum1; *(u64 *)(ctx + MC_CUM2) = p.cum2;
             ctx[MC_U] = C.U; ctx[MC_D] = C.D; ctx[MC_STRIDE32] = C.stride32; ctx[MC_GCHAIN] = p.first_chain + chain;
             ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = 1u; *(u64 *)(ctx + MC_GUARD) = p.guard_limit; *(u64 *)(ctx + MC_XW) = (u64)C.xw;   // (MC_W = 1: the exact run's own layout)
+            ctx[MC_CLIM] = p.commit_words; ctx[MC_CLIM + 1] = 0u;
             L.tables[4 * CQ_ORDERS] = (u64)p.clq; L.tables[4 * CQ_ORDERS + 1] = (u64)p.clq_pairs;
             L.tables[4 * CQ_ORDERS + 2] = (u64)(u32)p.cl_orders | ((u64)p.chg_cap << 32);
         }
@@ -536,11 +537,14 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
                     const u32 bit_clr = 1u << ((flg >> 20) & 31u), bit_set = 1u << ((flg >> 25) & 31u);
                     u32 nclr = w_clr & ~bit_clr, nset = w_set | bit_set;
                     if (wid_clr == wid_set) { nclr |= bit_set; nset = nclr; }
-                    if (lane == 0) {
+                    // (indices out of the exact run's record: held against the chain's sizes before anything is stored, as in the multi-wave kernel)
+                    const u32 slot = rdlane(sv, SR_DSLOT), was = rdlane(sv, SR_ID1), now = rdlane(sv, SR_ID2);
+                    const bool bad = max(wid_clr, wid_set) >= p.commit_words || ((flg & SRF_DMOVE) && (slot >= C.D || was >= C.U || now >= C.U));
+                    if (bad) pst |= 0x200u;
+                    else if (lane == 0) {
                         C.rows[wid_clr] = nclr;
                         C.rows[wid_set] = nset;
                         if (flg & SRF_DMOVE) {   // the slot's pair stops being reciprocal, the single edge's pair becomes so
-                            const u32 slot = rdlane(sv, SR_DSLOT), was = rdlane(sv, SR_ID1), now = rdlane(sv, SR_ID2);
                             slot_of[was] = FCM_NOSLOT;
                             slot_of[now] = slot;
                             C.dbl[slot] = now;
@@ -588,7 +592,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
         st_g[4] += rdlane(tl, OT_DMOVE); st_g[5] += rdlane(tl, OT_SUMK); if (nlen > st_g[6]) st_g[6] = nlen; st_g[7] |= stw;
         st_g[8] += rdlane(tl, OT_CPERM); st_g[9] += rdlane(tl, OT_CSWAP); st_g[10] += rdlane(tl, OT_CHANGES);
         st_g[12] += rdlane(tl, OT_WIDE); st_g[13] += rdlane(tl, OT_BIG);
-        st_g[14] += rdlane(tl, OT_PAIRS); st_g[15] += rdlane(tl, OT_SHARED);
+        st_g[16] += rdlane(tl, OT_PAIRS); st_g[17] += rdlane(tl, OT_SHARED);   // FCM_STAT_PAIRS, FCM_STAT_SHARED_ROWS
     }
 }
 

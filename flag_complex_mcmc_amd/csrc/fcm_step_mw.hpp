@@ -57,6 +57,13 @@
 #ifndef MW_MINW
 #define MW_MINW 8
 #endif
+// Ablation probes (tools/ablate.sh; WRONG RESULTS BY DESIGN, never in the product build): bits of MW_ABL leave a part of the
+// proposal out so that the bench shows what the chip spends on it -- 1: the evaluations, 2: the bitmap reads of the builds
+// (masks made up from the vertex ids), 4: the commit's global stores, 8: the loads of the two words a commit rewrites, 16: the
+// in-order wait (every wave decides when it is ready), 32: the vertex-list loads (lists made up).
+#ifndef MW_ABL
+#define MW_ABL 0
+#endif
 // Code-shape knobs.  They change nothing in what the kernel computes; they decide whether hipcc finds a clean
 // allocation at 64 VGPRs / 80 SGPRs for a given variant (tools/scratch_census.sh; the defaults below are what
 // tools/tune_knobs.sh found clean for every variant; `make EXTRA=-DMW_K_..=..` overrides them for all variants).  ZERO: the count registers are zeroed by instructions of their own.  LANE: the lane id
@@ -103,19 +110,21 @@
 // chain context, u32 words in LDS: what the out-of-line parts (table fill, exact run) need, so that the hot loop
 // does not have to keep it in registers
 enum { MC_ROWS = 0, MC_DBL = 2, MC_NB = 4, MC_ETAB = 6, MC_ROWS_BYTES = 8, MC_SEED = 10, MC_SAMPLED0 = 12, MC_CUM0 = 14, MC_CUM1 = 16,
-       MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_XW = 28, MC_WORDS = 30 };
+       MC_CUM2 = 18, MC_U = 20, MC_D, MC_STRIDE32, MC_GCHAIN, MC_MAXNW, MC_W, MC_GUARD = 26, MC_XW = 28, MC_CLIM = 30 /* u32 words of the chain's
+       mutable record: what a commit's word indices are held against */, MC_WORDS = 32 };
 
 // LDS map in u64 words:
-//   shared    E[9]: {count, inside-the-bounds flag (entry 0), bmin, bmax} | head | ctx[15] | vis[8] | tallies[2 u32] | ring[4W][7]
+//   shared    E[9]: {count, inside-the-bounds flag (entry 0), bmin, bmax} | head | ctx[16] | vis[8] | tallies[2 u32] | ring[4W][7]
 //             (<= 8 count entries: tmax <= 6; entry 8 = {0, 0, 0, ~0} is what the lanes without a count read)
 //   per wave  Hp[64] | arc list[64] | draw table: 28 entries of 14 u32 [196] | tallies[9]   (the arc list doubles as the
 //             exact run's per-lane results; tallies: 17 u32, MA_*)
 //   wide evaluator (one: only the token holder runs it)
-#define MW_SHARED_WORDS 61u
-#define MW_TALLY_OFF 60u                                     // [0] proposals that checked a record again under the token, [1] that waited for a staged record's decision
+#define MW_SHARED_WORDS 62u
+#define MW_TALLY_OFF 61u                                     // [0] proposals that checked a record again under the token, [1] that waited for a staged record's decision
 #define MW_HEAD_OFF 36u
 #define MW_CTX_OFF 37u
-#define MW_VIS_OFF 52u
+#define MW_VIS_OFF 53u
+static_assert(MW_CTX_OFF + MC_WORDS / 2 == MW_VIS_OFF && MW_VIS_OFF + 8u == MW_TALLY_OFF && MW_TALLY_OFF + 1u == MW_SHARED_WORDS, "shared LDS map");
 #define MW_TBL_WORDS 14u
 #ifndef MW_TBL_N
 #ifndef MW_TBL_N
@@ -147,6 +156,18 @@ __device__ __forceinline__ u64 mw_uni64(u64 v) { return (u64)mw_uni((u32)v) | ((
 template <bool ROWS128>
 __device__ __forceinline__ u64 mw_build(const rsrc_t rr, u32 stride32, u32 Lv, int s, int lane)
 {
+#if MW_ABL & 2   // (no bitmap reads: masks made up from the vertex ids, the pair itself one way)
+    {
+        u64 h = ((u64)Lv * 0x9E3779B97F4A7C15ull) ^ ((u64)Lv << 21);
+        h &= (h >> 7) | (h << 3);
+        h = lane < s ? (h & (s >= 64 ? ~0ull : ((1ull << s) - 1ull))) : 0ull;
+        const int k = s - 2;
+        h &= ~(1ull << lane);
+        if (lane == k + 1) h |= 1ull << k;
+        if (lane == k) h &= ~(1ull << (k + 1));
+        return h;
+    }
+#endif
     if constexpr (ROWS128) return build_local_rows128(rr, Lv, s, lane);
     else return build_local_loop16(rr, stride32, Lv, s, lane);
 }
@@ -534,7 +555,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     snap_point();   // (paths without a load of mutable state)
     // the two bitmap words a commit rewrites, read here -- lines the builds have just touched -- so that the commit is
     // two plain stores.  Issued last: the round trip runs beside the wait for the token instead of in front of it.
-    if (R.nonempty) {   // (through the descriptor: the word id goes into the scalar offset, no 64-bit address arithmetic)
+    if (R.nonempty && !(MW_ABL & 8)) {   // (through the descriptor: the word id goes into the scalar offset, no 64-bit address arithmetic)
         O.w_clr = __builtin_amdgcn_raw_buffer_load_b32(rr, 0, (int)(R.wid_clr * 4u), 0);
         O.w_set = __builtin_amdgcn_raw_buffer_load_b32(rr, 0, (int)(R.wid_set * 4u), 0);
     }
@@ -542,6 +563,9 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     // the record, before the evaluations: nothing of it stays in registers across them, and the chain's other waves can
     // hold it against their reads from now on (not if it is incomplete: they then wait for the exact run's)
     mw_stage(stage, R, lane, (rec_q << 4) | ((EXACT || O.need_exact) ? 0u : MS_STAGED));
+#if MW_ABL & 1
+    nev = 0;
+#endif
     if (nev) {
         int delta[MAXT + 1];
 #pragma unroll
@@ -842,6 +866,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             *(u64 *)(ctx + MC_CUM0) = p.cum0; *(u64 *)(ctx + MC_CUM1) = p.cum1; *(u64 *)(ctx + MC_CUM2) = p.cum2;
             ctx[MC_U] = C.U; ctx[MC_D] = C.D; ctx[MC_STRIDE32] = C.stride32; ctx[MC_GCHAIN] = p.first_chain + chain;
             ctx[MC_MAXNW] = (u32)maxnw; ctx[MC_W] = W; *(u64 *)(ctx + MC_GUARD) = p.guard_limit; *(u64 *)(ctx + MC_XW) = (u64)C.xw;
+            ctx[MC_CLIM] = p.commit_words; ctx[MC_CLIM + 1] = 0u;
         }
     }
     mw_barrier();
@@ -906,7 +931,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         bool hit = O.need_exact != 0u;
         u32 hitw;                                 // the same as one scalar word (as a lane mask it costs two spilled SGPRs and a select per use)
         const u32 nent = q - snap;                                            // <= 2W - 1
-        if (nent >= MW_VEC_MIN) {
+        if (nent >= MW_VEC_MIN && !(MW_ABL & 16)) {
             // several records: all at once and as soon as they are staged (out of line, W >= 4)
             hitw = mw_uni(mw_wait_staged(smem, wv, q, snap, O.Lv1, O.Lv2, hit ? 1u : 0u, W, sv));   // (0 / 1, wave-uniform, and said so: what follows branches on it with scalar branches)
         } else {
@@ -915,6 +940,9 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             const u32 wid_clr = rdlane(sv, SR_WCLR), wid_set = rdlane(sv, SR_WSET);
             u32 c = snap;
             for (;;) {
+#if MW_ABL & 16
+                break;
+#endif
                 const u32 h = mw_uni(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // h <= q
                 while (c < h && !hit) {
                     const u32 ev = lane < SR_WORDS ? ringL[(c & ring) * MW_REC_WORDS + lane] : 0u;
@@ -994,7 +1022,8 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         if (lane == 0) ctl[1] = (u32)t_head;   // (diagnostic: when the token was passed on; the next holder measures the hand-over against it)
 #endif
         __builtin_amdgcn_s_setprio(0);
-#if MW_PROBE == 9   // (timing probe: no commit stores -- wrong results by design)
+        u32 badw = 0u;                                                         // 0x200: a commit whose indices were out of range (not stored)
+#if MW_PROBE == 9 || (MW_ABL & 4)   // (timing probe: no commit stores -- wrong results by design)
         if (commit && q == 0xFFFFFFFFu) {
 #else
         if (commit) {
@@ -1004,10 +1033,18 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             const u32 bit_clr = 1u << ((flg >> 20) & 31u), bit_set = 1u << ((flg >> 25) & 31u);
             u32 nclr = w_clr & ~bit_clr, nset = w_set | bit_set;
             if (wid_clr == wid_set) { nclr |= bit_set; nset = nclr; }
-            if (lane == 0) {
+            // These are the hot path's only flat stores whose addresses come out of mutable data (the record; every load of
+            // mutable state goes through a clamping buffer descriptor or takes its index from a static table): hold the word
+            // indices against the chain's record and the slot and pair against D and U -- the token is gone, this is off the
+            // serial path -- and refuse instead of storing (status 0x200 -> FCM_ERR_INTERNAL at the next read-out).
+            const u32 clim = mw_uni(ctx[MC_CLIM]);
+            const u32 dslot = rdlane(sv, SR_DSLOT), id2 = rdlane(sv, SR_ID2);
+            const bool bad = max(wid_clr, wid_set) >= clim || (is_dmove && (dslot >= C.D || id2 >= C.U));
+            if (bad) badw = 0x200u;
+            else if (lane == 0) {
                 C.rows[wid_clr] = nclr;
                 C.rows[wid_set] = nset;
-                if (is_dmove) C.dbl[rdlane(sv, SR_DSLOT)] = rdlane(sv, SR_ID2);
+                if (is_dmove) C.dbl[dslot] = id2;
             }
         }
 #ifdef MW_STAMP
@@ -1034,9 +1071,13 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
             inc = lane_in(1ull << MA_SUMK) ? ((flg >> 8) & 0xFFFu) : inc;
             // a count never goes below zero (reference assert, src/lib.rs:65; counts stay far below 2^63, so a negative sum is that)
             const u32 below = (nonempty && (ballot((int)(u32)(ncnt >> 32) < 0) & 0xFFull)) ? 8u : 0u;
-            const u32 stw = rdlane(sv, SR_SUS) | below | ((rdlane(tv, 0) & 0xFEu) ? 4u : 0u);   // (move >= 2: this kernel has no clique moves)
+            const u32 stw = rdlane(sv, SR_SUS) | below | badw | ((rdlane(tv, 0) & 0xFEu) ? 4u : 0u);   // (move >= 2: this kernel has no clique moves)
             u32 orv = (nonempty && ncnt != 0ull) ? 1u : 0u;                   // lanes 0..7: count entry non-zero after this transition
+#if MW_PROBE >= 9 || MW_ABL   // (ablation / timing probes compute wrong results by design: their status word stays clean so that the bench can read the counters)
+            orv = lane_in(1ull << 8) ? 0u : orv;
+#else
             orv = lane_in(1ull << 8) ? stw : orv;
+#endif
             const u32 taddr = mw_lds_addr(tly) + (u32)lane * 4u;
             asm volatile("s_mov_b64 exec, 0xff\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, 0x1ff\n\tds_or_b32 %0, %2 offset:32\n\ts_mov_b64 exec, -1"
                          :: "v"(taddr), "v"(inc), "v"(orv) : "memory");

@@ -21,6 +21,8 @@
 #include <stdexcept>
 #include <string>
 #include <sys/stat.h>
+#include <ctime>
+#include <unistd.h>
 #include <thread>
 #include <exception>
 #include <memory>
@@ -350,26 +352,76 @@ public:
     }
     std::vector<uint8_t> edgebits(uint32_t chain) { const auto l = locate(chain); return shards_[l.first]->edgebits(l.second); }
     Graph graph(uint32_t chain) { const auto l = locate(chain); return shards_[l.first]->graph(l.second); }
-    /// one state file per shard: <fname> for a single shard (the single-device layout), <fname>.shard<r> otherwise
+    /// One state file per shard: <fname> for a single shard (the single-device layout), <fname>.shard<r> otherwise.  Every file
+    /// carries its place in the set (shard r of G, the run's chain count, the save's sample number as the set's id:
+    /// fcm_sampler_save_state_shard), so that a resume can check it has ONE complete save in hand.
     static std::string shard_file(const std::string &fname, size_t r, size_t n_shards) { return n_shards == 1 ? fname : fname + ".shard" + std::to_string(r); }
     void save_state(const std::string &fname, size_t sample_number)
     {
-        parallel([&](size_t r) { shards_[r]->save_state(shard_file(fname, r, shards_.size()), sample_number); });
+        const size_t G = shards_.size();
+        const uint64_t set_id = ((uint64_t)sample_number << 32) ^ (uint64_t)time(nullptr) ^ ((uint64_t)getpid() << 20);   // one number per save
+        // all shards to <file>.new first, moved into place only once every one of them is written: a failure half-way leaves
+        // the previous save whole (the moves themselves are not atomic as a set: the loader checks the set's id)
+        parallel([&](size_t r) {
+            check(fcm_sampler_save_state_shard(shards_[r]->raw(), (shard_file(fname, r, G) + ".new").c_str(), sample_number, (uint32_t)r, (uint32_t)G, n_chains_, set_id));
+        });
+        for (size_t r = 0; r < G; ++r) {
+            const std::string f = shard_file(fname, r, G);
+            if (rename((f + ".new").c_str(), f.c_str()) != 0) throw Error(FCM_ERR_IO, "moving " + f + ".new into place failed");
+        }
     }
+    /// Resume: the number of shards comes from the FILES, not from the device list -- shard r goes to devices[r % devices.size()]
+    /// (a device may hold several shards, each with its own handle and host thread; a state saved on 4 handles resumes on 2
+    /// devices or on 1, one saved on 2 resumes on 3 with the third device idle).  Fails loudly if a shard is missing, if the
+    /// files are not of one save (set id, sample number, seed) or if their chain ranges do not tile 0 .. total-1.
     static std::pair<size_t, MultiDeviceSampler> load_state(const std::string &fname, const std::vector<int> &devices)
     {
-        std::vector<std::unique_ptr<MCMCSampler>> shards;
-        std::vector<int> devs;
-        size_t sample_number = 0;
-        for (size_t r = 0; r < devices.size(); ++r) {
-            const std::string f = shard_file(fname, r, devices.size());
-            if (r > 0) { FILE *t = fopen(f.c_str(), "rb"); if (!t) break; fclose(t); }   // fewer shards than devices: chains < devices
-            auto ls = MCMCSampler::load_state(f, devices[r]);
-            sample_number = ls.first;
-            shards.emplace_back(new MCMCSampler(std::move(ls.second)));
-            devs.push_back(devices[r]);
+        if (devices.empty()) throw Error(FCM_ERR_INVALID, "no devices");
+        auto exists = [](const std::string &f) { FILE *t = fopen(f.c_str(), "rb"); if (!t) return false; fclose(t); return true; };
+        fcm_state_info first{};
+        const bool sharded = exists(fname + ".shard0");
+        if (sharded && exists(fname)) {
+            // both layouts on disk (a run saved on one handle, then on several, or the other way round): take the newer save, by sample number
+            fcm_state_info one{}, many{};
+            check(fcm_state_file_info(fname.c_str(), &one));
+            check(fcm_state_file_info((fname + ".shard0").c_str(), &many));
+            first = many.sample_number >= one.sample_number ? many : one;
+        } else {
+            check(fcm_state_file_info((sharded ? fname + ".shard0" : fname).c_str(), &first));
         }
-        return {sample_number, MultiDeviceSampler(std::move(shards), std::move(devs))};
+        const size_t G = first.shard_count;   // (from the file, not from the device list)
+        std::vector<fcm_state_info> info(G);
+        uint64_t at = first.shard_index == 0 ? first.first_chain_id : 0;   // (a single handle's file may start at any global chain id: first_chain_id of its config)
+        for (size_t r = 0; r < G; ++r) {
+            const std::string f = shard_file(fname, r, G);
+            if (!exists(f)) throw Error(FCM_ERR_IO, f + ": shard " + std::to_string(r) + " of " + std::to_string(G) + " is missing");
+            check(fcm_state_file_info(f.c_str(), &info[r]));
+            const fcm_state_info &h = info[r];
+            if (h.shard_index != r || h.shard_count != G || h.total_chains != first.total_chains || h.set_id != first.set_id || h.sample_number != first.sample_number
+                || h.seed != first.seed || h.n != first.n)
+                throw Error(FCM_ERR_IO, f + ": not a shard of the same save as " + shard_file(fname, 0, G) + " (shard index / count, chains, set id, sample number, seed or graph differ)");
+            if (h.first_chain_id != at) throw Error(FCM_ERR_IO, f + ": its chains start at " + std::to_string(h.first_chain_id) + ", the shards before it end at " + std::to_string(at));
+            at += h.n_chains;
+        }
+        if (at != first.total_chains) throw Error(FCM_ERR_IO, fname + ": the shards hold " + std::to_string(at) + " chains, the run had " + std::to_string(first.total_chains));
+        std::vector<std::unique_ptr<MCMCSampler>> shards(G);
+        std::vector<int> devs(G);
+        for (size_t r = 0; r < G; ++r) devs[r] = devices[r % devices.size()];
+        {   // every shard on its own thread, like everything else here
+            std::vector<std::exception_ptr> err(G);
+            std::vector<std::thread> th;
+            auto run = [&](size_t r) {
+                try { auto ls = MCMCSampler::load_state(shard_file(fname, r, G), devs[r]); shards[r].reset(new MCMCSampler(std::move(ls.second))); }
+                catch (...) { err[r] = std::current_exception(); }
+            };
+            size_t started = 1;
+            try { for (; started < G; ++started) th.emplace_back(run, started); } catch (...) {}
+            run(0);
+            for (size_t r = started; r < G; ++r) run(r);
+            for (auto &t : th) t.join();
+            for (auto &e : err) if (e) std::rethrow_exception(e);
+        }
+        return {(size_t)first.sample_number, MultiDeviceSampler(std::move(shards), std::move(devs))};
     }
 
 private:

@@ -19,7 +19,10 @@ def shard_range(total_chains, rank, world_size):
 def gather_counts(counts, stats, device=None):
     """All-gather per-chain flag_count vectors [c_local, nc] and counters
     [c_local, ns] (uint64) from every rank; returns numpy arrays ordered by
-    global chain id.  Every rank must hold the same c_local (weak scaling)."""
+    global chain id.  Ranks may hold different numbers of chains (shard_range's
+    blocks are unequal when the total does not divide, and the last ranks may hold
+    none): every rank's block is padded to the largest before the one all_gather
+    and cut back to its own length afterwards."""
     import torch
     import torch.distributed as dist
 
@@ -28,12 +31,20 @@ def gather_counts(counts, stats, device=None):
     world = dist.get_world_size()
     # uint64 -> int64 bit pattern: collectives do not care, and RCCL has no u64 all_gather dtype in torch
     local = np.concatenate([np.asarray(counts, np.uint64), np.asarray(stats, np.uint64)], axis=1).view(np.int64)
-    t = torch.from_numpy(np.ascontiguousarray(local))
-    if device is not None:
-        t = t.to(device)
-    out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+    dev = device if device is not None else "cpu"
+    rows = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    all_rows = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_rows, rows)
+    all_rows = [int(x) for x in all_rows.cpu().tolist()]
+    most = max(all_rows)
+    t = torch.zeros((most, local.shape[1]), dtype=torch.int64, device=dev)
+    if local.shape[0]:
+        t[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+    out = torch.empty((world * most, local.shape[1]), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(out, t)
     arr = out.cpu().numpy().view(np.uint64)
+    if any(r != most for r in all_rows):
+        arr = np.concatenate([arr[r * most: r * most + all_rows[r]] for r in range(world)], axis=0)
     nc = np.asarray(counts).shape[1]
     return arr[:, :nc].copy(), arr[:, nc:].copy()
 

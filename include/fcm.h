@@ -185,8 +185,10 @@ uint64_t fcm_sampler_sample_distance(const fcm_sampler *s);
  * (never shrinks, src/lib.rs:72-74,89-91). */
 int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 
-/* Per-chain counters, out[n_chains][FCM_NSTATS]. */
-#define FCM_NSTATS 16
+/* Per-chain counters, out[n_chains][FCM_NSTATS].  Every slot means the same thing on every sampler; a slot that the
+ * sampler's kernel does not count stays 0 (RECHECK / HELD: simple-move samplers on the multi-wave kernel only; CPERM,
+ * CSWAP, CHANGES, PAIRS, SHARED_ROWS: samplers with clique moves only). */
+#define FCM_NSTATS 18
 #define FCM_STAT_SAMPLED 0    /* MCMCSampler::sampled (src/lib.rs:176) */
 #define FCM_STAT_ACCEPTED 1   /* MCMCSampler::accepted (src/lib.rs:177) */
 #define FCM_STAT_EMPTY 2      /* proposals whose transition was empty */
@@ -194,7 +196,8 @@ int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 #define FCM_STAT_DMOVE 4      /* non-empty double_edge_move proposals */
 #define FCM_STAT_SUM_K 5      /* sum over evaluated edges of |N(a) cap N(b)| */
 #define FCM_STAT_COUNT_LEN 6
-#define FCM_STAT_STATUS 7     /* 0 ok; non-zero = device-side check failed */
+#define FCM_STAT_STATUS 7     /* 0 ok; non-zero = device-side check failed (bit 0x200: a commit's word or slot index was out of range and
+                                 was not stored) */
 #define FCM_STAT_CPERM 8      /* non-empty clique_permute proposals */
 #define FCM_STAT_CSWAP 9      /* non-empty clique_swap proposals */
 #define FCM_STAT_CHANGES 10   /* directed edges changed by clique-move proposals */
@@ -204,11 +207,9 @@ int fcm_sampler_get_counts(fcm_sampler *s, uint64_t *out, int32_t *count_len);
 #define FCM_STAT_BIG 13       /* evaluated local sets of more than 48 vertices (second trip of the whole-row build) */
 #define FCM_STAT_RECHECK 14   /* multi-wave kernel, W >= 4: proposals that had to check a record again under the token (it was decided on an exact run after they had checked it as staged) */
 #define FCM_STAT_HELD 15      /* multi-wave kernel, W >= 4: proposals that waited for the decision of a staged record in conflict with their reads */
-/* Samplers with clique moves run other kernels, which have neither; there the two slots count what the traffic model of a
- * clique move needs (bench.py): */
-#define FCM_STAT_PAIRS 14        /* clique moves: vertex pairs with a changed direction (one local build each; FCM_STAT_CHANGES counts directions) */
-#define FCM_STAT_SHARED_ROWS 15  /* clique_permute: (changed pairs - 1) x clique order per move -- rows of the clique's own vertices that the builds
-                                    of one move read more than once */
+#define FCM_STAT_PAIRS 16        /* clique moves: vertex pairs with a changed direction (one local build each; FCM_STAT_CHANGES counts directions) */
+#define FCM_STAT_SHARED_ROWS 17  /* clique_permute: (changed pairs - 1) x clique order per move -- rows of the clique's own vertices that the builds
+                                    of one move read more than once (bench.py's traffic model of a clique move) */
 int fcm_sampler_get_stats(fcm_sampler *s, uint64_t *out);
 
 /* Directed edge list of one chain's current graph, ascending (from,to). */
@@ -272,6 +273,20 @@ int fcm_sampler_single_edge_flip(fcm_sampler *s, uint32_t chain, uint64_t x, fcm
 /* ------------------------------------------------------------------------ */
 int fcm_sampler_save_state(fcm_sampler *s, const char *path, uint64_t sample_number);
 int fcm_sampler_load_state(const char *path, int device, fcm_sampler **out, uint64_t *sample_number);
+/* A run whose chains are spread over several handles (one per device) is saved as one file per handle.  Every file of  */
+/* the set says which shard of how many it is, how many chains the whole run has and carries the set's id (any number   */
+/* the caller picks per save, e.g. sample_number: files of two different saves must not be mixed); with the handle's     */
+/* first_chain_id and n_chains that is enough to check, at resume, that the files present tile chains 0..total-1 of ONE  */
+/* save -- whatever the number of devices then is.  fcm_sampler_save_state = shard 0 of 1 of a run whose chains end with */
+/* the handle's (total_chains = first_chain_id + n_chains).                                                              */
+int fcm_sampler_save_state_shard(fcm_sampler *s, const char *path, uint64_t sample_number, uint32_t shard_index, uint32_t shard_count,
+                                 uint64_t total_chains, uint64_t set_id);
+typedef struct {
+    uint64_t sample_number, total_chains, set_id, seed;
+    uint32_t n, n_chains, first_chain_id, shard_index, shard_count;
+} fcm_state_info;
+/* The header of a state file, without loading it. */
+int fcm_state_file_info(const char *path, fcm_state_info *out);
 
 /* Diagnostic: per-chain phase cycle sums of a -DFCM_STAMP build of the step kernel
  * (tools/run_stamps.sh); all zero in the product build.  out[n_chains][8]. */
@@ -302,6 +317,8 @@ typedef struct {
                                   vertices and at most two common neighbours per pair on average, under the simple moves (BASELINE
                                   configs[4]: 250 KB per chain instead of 115 MB).  Environment FCM_SPARSE=0 / 1 overrides.  Results do
                                   not depend on it. */
+    uint32_t cooperative_clique_kernel;   /* 1: move mixes with clique moves run on fcm_step_cq_kernel (waves_per_chain of them share a move's
+                                             changed pairs; it may be 1), 0: on the one-wave kernel's clique path (or no clique moves) */
 } fcm_sampler_info;
 int fcm_sampler_get_info(const fcm_sampler *s, fcm_sampler_info *out);
 /* The Bounds the sampler checks against (MCMCSampler::bounds, src/lib.rs:170). */

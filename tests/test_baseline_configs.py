@@ -157,3 +157,58 @@ def test_multi_wave_soak_configs_1_and_4(fcm, cfg, chains, props):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.soak(cfg, chains, props, say=lambda m: None)
+
+
+# ---- the stated per-GPU shares of configs[2] and configs[3], as bench.py runs them ------------------------
+def _recount_ok(fcm, s, chain):
+    fc = s.flag_count(chain)
+    while fc and fc[-1] == 0:   # flag_count never shrinks in length (src/lib.rs:72-74)
+        fc.pop()
+    return s.graph(chain).flagser_count() == fc and s.bounds.check(s.flag_count(chain))
+
+
+def _pick_rare(stats, want):
+    """Chains whose run hit the rare paths (wide evaluations, re-runs, big local sets), as tests/test_gpu_parity.py picks them."""
+    order = np.lexsort((-stats["n_big"].astype(np.int64), -stats["n_redo"].astype(np.int64), -stats["n_wide"].astype(np.int64)))
+    return [int(c) for c in order[:want]]
+
+
+def test_config2_stated_share_4096_chains_w2(fcm, oracle):
+    """BASELINE configs[2] at its stated size -- ER n = 1000 p = 0.10 seed 0, 4096 chains on one GPU, the residency the
+    bench line depends on (W = 2, 16 workgroups per CU at the 10-KiB LDS budget) -- in front of a recount and of oracle
+    twins: 2000 proposals per chain, from-scratch GPU recount of 3 chains, oracle twins (tolerance 0) on the 4 chains the
+    rare-path counters pick.  Reference loop: src/lib.rs:181-194."""
+    n, nprop = 1000, 2000
+    e = fcm.graphs.random_with_p(n, 0.10, 0)
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, b_g, n_chains=4096, seed=0)
+    assert s.info["waves_per_chain"] == 2 and not s.info["sparse_state"]
+    s.step(nprop)
+    st = s.stats()
+    assert (st["status"] == 0).all() and (st["sampled"] == nprop).all()
+    assert (st["n_empty"] + st["n_flip"] + st["n_dmove"] == nprop).all()
+    for c in (0, 2047, 4095):
+        assert _recount_ok(fcm, s, c), c
+    for c in _pick_rare(st, 4):
+        tw = oracle.Chain(go, b_o, seed=0, chain_id=c)
+        tw.step(nprop)
+        compare_chain(s, c, tw, ctx=("configs[2] stated share", c))
+
+
+def test_config3_stated_share_1024_chains_w16(fcm, oracle):
+    """BASELINE configs[3]'s per-GPU share -- ER n = 4000 p = 0.05 seed 0, 1024 chains (8192 over 8 GPUs), W = 16: the
+    workgroups do not all fit and run in rounds -- 1000 proposals per chain, recount of 3 chains, oracle twins on 4."""
+    n, nprop = 4000, 1000
+    e = fcm.graphs.random_with_p(n, 0.05, 0)
+    gg, go, b_g, b_o = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, b_g, n_chains=1024, seed=0)
+    assert s.info["waves_per_chain"] == 16
+    s.step(nprop)
+    st = s.stats()
+    assert (st["status"] == 0).all() and (st["sampled"] == nprop).all()
+    for c in (0, 511, 1023):
+        assert _recount_ok(fcm, s, c), c
+    for c in _pick_rare(st, 4):
+        tw = oracle.Chain(go, b_o, seed=0, chain_id=c)
+        tw.step(nprop)
+        compare_chain(s, c, tw, ctx=("configs[3] stated share", c))

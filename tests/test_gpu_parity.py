@@ -488,7 +488,7 @@ def test_save_state_load_state_resumes_exactly(fcm, oracle, tmp_path):
     for s in (a, b):
         assert (s.flag_counts() == straight.flag_counts()).all()
         for k, v in straight.stats().items():
-            if k not in ("n_redo", "n_recheck", "n_held", "n_pairs", "n_shared_rows"):   # timing diagnostics of the multi-wave kernel (proposals re-run under the token; the last two: the same slots under their clique-sampler names), not chain state
+            if k not in ("n_redo", "n_recheck", "n_held"):   # timing diagnostics of the multi-wave kernel (proposals re-run under the token, records re-checked or waited for), not chain state
                 assert (s.stats()[k] == v).all(), k
         for c in range(5):
             assert (s.edges(c) == straight.edges(c)).all()
@@ -888,3 +888,55 @@ def test_count_kernel_counts_past_2_to_31_per_edge(fcm):
     want = [math.comb(parts, d + 1) * size ** (d + 1) * math.factorial(d + 1) for d in range(parts)]
     assert want[6] > 2 ** 31
     assert fcm.Graph.from_edges(n, e).flagser_count() == want
+
+
+def test_commit_guard_refuses_out_of_range_indices(fcm, monkeypatch):
+    """The commit's flat stores (two bitmap words, one slot of the reciprocal list) take their indices out of the
+    proposal's record; the kernels hold them against the chain's sizes before storing and raise status 0x200 instead
+    (VERDICT r3 item 1).  The test hook FCM_TEST_COMMIT_LIMIT lowers the limit the word indices are held
+    against to one word, so that every commit beyond word 0 is "out of range": nothing is stored, the run fails loudly
+    with FCM_ERR_INTERNAL at the next read-out.  Multi-wave kernel (W = 2, 8), its sparse-state variant, and the simple
+    moves of the cooperative clique kernel."""
+    from flag_complex_mcmc_amd import graphs
+    n = 300
+    e = graphs.random_with_p(n, 0.12, seed=8)
+    g = fcm.Graph.from_edges(n, e)
+    for mw, weights in (("2", fcm.MOVE_DISTRIBUTION_SIMPLE), ("8", fcm.MOVE_DISTRIBUTION_SIMPLE), ("", fcm.MOVE_DISTRIBUTION)):
+        if mw:
+            monkeypatch.setenv("FCM_MW", mw)
+        else:
+            monkeypatch.delenv("FCM_MW", raising=False)
+            monkeypatch.setenv("FCM_CQ", "1")
+        monkeypatch.delenv("FCM_TEST_COMMIT_LIMIT", raising=False)
+        fc = g.flagser_count()
+        b = fcm.Bounds.calculate(g, fc, fcm.Bounds.target(fc, 0.01))
+        ok = fcm.MCMCSampler(g, b, n_chains=3, seed=1, move_weights=weights)
+        ok.step(400)
+        assert (ok.stats()["status"] == 0).all() and (ok.stats()["accepted"] > 0).all()
+        monkeypatch.setenv("FCM_TEST_COMMIT_LIMIT", "1")
+        bad = fcm.MCMCSampler(g, b, n_chains=3, seed=1, move_weights=weights)
+        before = bad.edges(0).copy()
+        bad.step(400)
+        with pytest.raises(fcm.FcmError) as ei:
+            bad.stats()
+        assert ei.value.code == 8 and "0x200" in str(ei.value), str(ei.value)
+        monkeypatch.delenv("FCM_TEST_COMMIT_LIMIT", raising=False)
+    # sparse state (two bits per adjacent pair): the same guard on the record's words
+    monkeypatch.setenv("FCM_MW", "8")
+    monkeypatch.setenv("FCM_SPARSE", "1")
+    monkeypatch.delenv("FCM_CQ", raising=False)
+    n2 = 1200
+    e2 = graphs.random_edge_draws(n2, 9000, 3)
+    g2 = fcm.Graph.from_edges(n2, e2)
+    fc2 = g2.flagser_count()
+    b2 = fcm.Bounds.calculate(g2, fc2, fcm.Bounds.target(fc2, 0.01))
+    ok = fcm.MCMCSampler(g2, b2, n_chains=2, seed=1)
+    if ok.info["sparse_state"]:
+        ok.step(500)
+        assert (ok.stats()["status"] == 0).all()
+        monkeypatch.setenv("FCM_TEST_COMMIT_LIMIT", "1")
+        bad = fcm.MCMCSampler(g2, b2, n_chains=2, seed=1)
+        bad.step(500)
+        with pytest.raises(fcm.FcmError) as ei:
+            bad.stats()
+        assert ei.value.code == 8 and "0x200" in str(ei.value)

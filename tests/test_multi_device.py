@@ -112,3 +112,82 @@ def test_sample_cli_devices_list_equals_one_device(fcm, golden_dir, tmp_path):
     assert "flag count: %s" % s.flag_count(0) in r2.stdout
     n1, sh1 = fcm.MCMCSampler.load_state(str(st) + ".shard1")
     assert n1 == 5 and (sh1.flag_counts() == s.flag_counts()[3:]).all()
+
+
+def test_resume_takes_the_shard_count_from_the_files(fcm, oracle, tmp_path):
+    """a state saved on 2 handles resumes on 1 device and on 3 -- the number of shards, their order and
+    the run's chain count come from the files (fcm_sampler_save_state_shard / fcm_state_file_info), not from the device
+    list given at resume time -- and ends where the unsharded run ends.  A missing shard, shards of two different saves
+    and shards that do not tile the run's chains are refused loudly."""
+    n = 250
+    e = fcm.graphs.random_with_p(n, 0.1, seed=5)
+    gg, go, bg, bo = setup_pair(fcm, oracle, n, e)
+    straight = fcm.MCMCSampler(gg, bg, n_chains=7, seed=4)
+    straight.step(1500)
+    two = fcm.MultiDeviceSampler(gg, bg, 7, devices=[0, 0], seed=4)
+    two.step(600)
+    f = str(tmp_path / "run.state")
+    two.save_state(f, sample_number=3)
+    assert os.path.exists(f + ".shard0") and os.path.exists(f + ".shard1") and not os.path.exists(f) and not os.path.exists(f + ".shard0.new")
+    info = fcm.MultiDeviceSampler.state_file_info(f + ".shard1")
+    assert (info["shard_index"], info["shard_count"], info["total_chains"], info["first_chain_id"], info["n_chains"], info["sample_number"]) == (1, 2, 7, 4, 3, 3)
+    for devices in ([0], [0, 0, 0], [0, 0]):
+        num, m = fcm.MultiDeviceSampler.load_state(f, devices)
+        assert num == 3 and m.n_chains == 7 and m.ranges == [(0, 4), (4, 7)] and len(m.shards) == 2
+        m.step(900)
+        assert (m.flag_counts() == straight.flag_counts()).all()
+        for c in (0, 3, 4, 6):
+            assert (m.edges(c) == straight.edges(c)).all() and (m.double_slots(c) == straight.double_slots(c)).all()
+    # a state saved on 4 handles and resumed with two devices: all four shards, two per device
+    four = fcm.MultiDeviceSampler(gg, bg, 7, devices=[0, 0, 0, 0], seed=4)
+    four.step(600)
+    f4 = str(tmp_path / "run4.state")
+    four.save_state(f4, sample_number=9)
+    num, m = fcm.MultiDeviceSampler.load_state(f4, [0, 0])
+    assert num == 9 and len(m.shards) == 4 and m.n_chains == 7
+    m.step(900)
+    assert (m.flag_counts() == straight.flag_counts()).all()
+    # a missing shard
+    os.rename(f4 + ".shard2", f4 + ".gone")
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MultiDeviceSampler.load_state(f4, [0, 0])
+    assert "shard 2 of 4 is missing" in str(ei.value)
+    os.rename(f4 + ".gone", f4 + ".shard2")
+    # shards of two different saves (same layout, another sample number)
+    four.step(10)
+    four.save_state(str(tmp_path / "later.state"), sample_number=10)
+    os.replace(str(tmp_path / "later.state.shard3"), f4 + ".shard3")
+    with pytest.raises(fcm.FcmError) as ei:
+        fcm.MultiDeviceSampler.load_state(f4, [0])
+    assert "not a shard of the same save" in str(ei.value)
+    # a single-handle file resumes through the same door, on any device list
+    straight2 = fcm.MCMCSampler(gg, bg, n_chains=7, seed=4)
+    straight2.step(600)
+    f1 = str(tmp_path / "one.state")
+    straight2.save_state(f1, 2)
+    num, m = fcm.MultiDeviceSampler.load_state(f1, [0, 0, 0])
+    assert num == 2 and len(m.shards) == 1 and m.n_chains == 7
+    m.step(900)
+    assert (m.flag_counts() == straight.flag_counts()).all()
+
+
+def test_sample_cli_resumes_two_shards_on_one_device(fcm, golden_dir, tmp_path):
+    """The same through the `sample` binary: saved with --devices 0,0, continued with --device 0 and with --devices 0,0,0."""
+    exe = os.path.join(os.path.dirname(fcm.LIB_PATH), "sample")
+    flag = os.path.join(golden_dir, "bug_calc_relax_de.flag")
+    base = [exe, "-l", "lab", "-s", "2", "--samples-store-dir", str(tmp_path / "samples"), "--state-store-dir", str(tmp_path / "state")]
+    r = subprocess.run(base + ["-i", flag, "--simple", "--chains", "5", "--sample-distance", "150", "-n", "2", "--devices", "0,0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    st = str(tmp_path / "state" / "sampler-lab-002.state")
+    s = fcm.initialize_new_sampler(flag, target_relaxation=0.01, seed=2, n_chains=5, sample_distance=150)
+    for _ in range(4):
+        s.next()
+    import shutil
+    for tag, devargs in (("one", ["--device", "0"]), ("three", ["--devices", "0,0,0"])):
+        d = tmp_path / ("state_" + tag)
+        shutil.copytree(tmp_path / "state", d)
+        r2 = subprocess.run([exe, "-c", str(d / "sampler-lab-002.state"), "-l", "lab", "-s", "2", "-n", "2", "--samples-store-dir", str(tmp_path / ("s_" + tag)),
+                             "--state-store-dir", str(d)] + devargs, capture_output=True, text=True, timeout=300)
+        assert r2.returncode == 0, r2.stdout + r2.stderr
+        assert "5 chains on 2 handles" in r2.stdout and "flag count: %s" % s.flag_count(0) in r2.stdout, r2.stdout
+    assert os.path.exists(st + ".shard0")
