@@ -310,7 +310,7 @@ __device__ __forceinline__ CliqueResult clique_setup(const CliqueTables &p, cons
 template <int MAXT, bool XW>
 __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u32 *rows, const rsrc_t rrows, u64 *smem, const CliqueLds CL, int move,
                                                        u32 w1, u64 x64, u64 step, u32 gchain, u32 k0, u32 k1, int lane, int tmax,
-                                                       int maxnw, int (&delta)[MAXT + 1], EvScal &es, u64 *sacc, u64 *stt, FcmGuard *guard = nullptr)
+                                                       int maxnw, fcm_acc_t<MAXT> (&delta)[MAXT + 1], EvScal &es, u64 *sacc, u64 *stt, FcmGuard *guard = nullptr)
 {
     const CliqueTables T = clique_tables(p);
     CliqueResult res = clique_setup(T, rows, CL, move, w1, x64, step, gchain, k0, k1, lane, sacc, stt);

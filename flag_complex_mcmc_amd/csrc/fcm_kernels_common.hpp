@@ -34,6 +34,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "fcm_device.hpp"
 
 typedef unsigned long long u64;
@@ -390,11 +391,8 @@ __device__ __forceinline__ u64 build_local_rows128(const rsrc_t rsrc, u32 Lv, in
 #ifndef FCM_SEAT_BRANCHY
 #define FCM_SEAT_BRANCHY 0   // 1: pick 32-bit halves by scalar branches (fewer VALU, more SALU and branches)
 #endif
-#ifndef FCM_SEAT_VEC
-#define FCM_SEAT_VEC 8       // extras up to which the seating runs as vector code (beyond: the wave-uniform loops)
-#endif
 #ifndef FCM_EVAL_V2
-#define FCM_EVAL_V2 1        // round 4: the evaluator's scalar-heavy parts as vector code (the CU's one scalar unit is what this kernel family saturates first)
+#define FCM_EVAL_V2 1        // round 4: branch-free class select; nodes with a single child sit the walk out
 #endif
 
 struct Cls { u64 P, M, S; };
@@ -469,6 +467,13 @@ __device__ __forceinline__ void visit(u64 cand, const u64 *Hp, int tmax, int sig
 // (fcm_count_guard).  Either way a status bit is raised and the run fails loudly at the next read-out instead of
 // returning wrapped counts.  FcmGuard::limit = 2^31 - 1 (FcmStepParams::guard_limit; a test hook lowers it).
 struct FcmGuard { u64 limit; u32 tripped; };
+// Per-lane accumulators of the walk: 32 bits in the kernels with up to 6 tracked levels (guards above), 64 bits in the generic
+// deep ones (MAXT >= 7) -- since round 4: with 32-bit counts their bound tripped on every evaluation of a dense graph of a
+// hundred vertices and each was then redone by the wave-uniform wide evaluator, 37 ms per proposal (tools/cliff_case.py,
+// DESIGN.md 7).  With 64-bit counts the bound only guards 2^62.
+template <int MAXT> using fcm_acc_t = std::conditional_t<(MAXT >= 7), long long, int>;
+__device__ __forceinline__ int wave_sum_acc(int v) { return wave_sum_i32(v); }
+__device__ __forceinline__ long long wave_sum_acc(long long v) { return wave_sum_i64(v); }
 __device__ __forceinline__ void fcm_count_guard(int nch, int tp, int tmax, FcmGuard *g)
 {
     if (!g) return;
@@ -482,12 +487,16 @@ __device__ __forceinline__ void fcm_count_guard(int nch, int tp, int tmax, FcmGu
     const u64 mm = (u64)(u32)__builtin_amdgcn_readlane(m, 63);
     const u64 lim = g->limit;
     u64 b = (u64)(u32)tp;
-    for (int t = 3; t <= tmax && b <= lim; ++t) b *= mm;
+    // b <- b * mm per further level, stopped before the product can pass 64 bits (bits(b) + bits(mm) <= 63 keeps it below 2^63)
+    for (int t = 3; t <= tmax && b <= lim; ++t) {
+        if ((64 - __clzll((long long)b)) + (64 - __clzll((long long)(mm | 1ull))) > 63) { b = ~0ull; break; }
+        b *= mm;
+    }
     if (b > lim) g->tripped = 1u;
 }
 
 template <int MAXT>
-__device__ __forceinline__ void fcm_lane_guard(const int (&delta)[MAXT + 1], FcmGuard &g)
+__device__ __forceinline__ void fcm_lane_guard(const fcm_acc_t<MAXT> (&delta)[MAXT + 1], FcmGuard &g)
 {
     if constexpr (MAXT == 6) {
         int m = 0;
@@ -510,7 +519,7 @@ struct EvScal { int d1, d2; };
 // The list sits behind Hp (FCM_PAIR_CAP 16-bit entries).
 #define FCM_PAIR_CAP 256
 template <int MAXT>
-__device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int tmax, int sign, int lane, int (&delta)[MAXT + 1], EvScal &es,
+__device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int tmax, int sign, int lane, fcm_acc_t<MAXT> (&delta)[MAXT + 1], EvScal &es,
                                            u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
 {
     u32 dummy = 0;
@@ -543,7 +552,7 @@ __device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int 
                     const u32 e = rd[pi];
                     nc = Hp[e & 0xFFu] & Hp[e >> 8];
                 }
-                if (nc) visit<2, MAXT, false>(nc, Hp, tmax, sign, delta, dummy);
+                if (nc) visit<2, MAXT, false, fcm_acc_t<MAXT>>(nc, Hp, tmax, sign, delta, dummy);
             }
             FCM_STAMP_PTR(5);                                      // (flips-only diagnostic) arcs and deeper levels
         } else {
@@ -551,7 +560,7 @@ __device__ __forceinline__ void walk_nodes(u32 rlo, u32 rhi, const u64 *Hp, int 
             const u64 row = (u64)rlo | ((u64)rhi << 32);
             for (u64 c = row; c; c &= c - 1) {
                 const u64 nc = row & Hp[__ffsll((long long)c) - 1];
-                if (nc) visit<2, MAXT, false>(nc, Hp, tmax, sign, delta, dummy);
+                if (nc) visit<2, MAXT, false, fcm_acc_t<MAXT>>(nc, Hp, tmax, sign, delta, dummy);
             }
         }
     }
@@ -580,9 +589,8 @@ __device__ __forceinline__ void seat_bit(u32 blo, u32 bhi, u32 &rlo, u32 &rhi, i
 // endpoints.  Requires extras_fit(c, k+2).  Levels 1 and 2 go to `es`, deeper ones to `delta` (per lane).
 template <int MAXT>
 __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k, int tmax, int sign, int lane,
-                                           int (&delta)[MAXT + 1], EvScal &es, u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
+                                           fcm_acc_t<MAXT> (&delta)[MAXT + 1], EvScal &es, u64 *sacc = nullptr, u64 *stt = nullptr, FcmGuard *guard = nullptr)
 {
-    const int s = k + 2;
     const u64 uv = 3ull << k;
     const u64 prim1 = c.M & ~c.P, prim2 = c.S & ~(c.P | c.M);
     const u64 xm = c.P & c.M, xs = c.S & (c.P | c.M);  // vertices that also need an M node / an S node
@@ -591,70 +599,29 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
     u32 blo = (u32)myH & ~(u32)uv, bhi = (u32)(myH >> 32) & ~(u32)(uv >> 32);
     const u64 gprim = c.P | prim1 | prim2;
     u32 rlo, rhi;
-#if FCM_EVAL_V2
-    // The extras as vector code.  Extra r (the vertices of xm ascending, then those of xs) is node k + r.  With up to
-    // FCM_SEAT_VEC extras -- two on average on the headline graph -- the lanes do all of it among themselves through a few
-    // words of LDS (the arc list's place, free until the scatter): an extra's lane leaves its raw mask and its own index at its
-    // rank (v_mbcnt), the seat's lane picks the mask up, and every lane moves, for each extra, bit `orig` of its mask to bit
-    // k + r of its row by a per-lane shift.  No wave-uniform loop, two exec-masked stores: the scalar loops this replaces
-    // cost 18 scalar instructions per extra (tools/bb_census.py), on the CU's one scalar unit.
-    const u64 xa = xm | xs;
-    const int nm = __popcll(xm), ne = nm + __popcll(xs);
-    if (xa != 0ull && ne <= FCM_SEAT_VEC) {
-        u64 *seatbuf = Hp + WAVE;
-        unsigned char *olist = (unsigned char *)(seatbuf + 56);
-        const u32 rkm = __builtin_amdgcn_mbcnt_hi((u32)(xm >> 32), __builtin_amdgcn_mbcnt_lo((u32)xm, 0u));
-        const u32 rks = __builtin_amdgcn_mbcnt_hi((u32)(xs >> 32), __builtin_amdgcn_mbcnt_lo((u32)xs, (u32)nm));
-        const u64 braw = (u64)blo | ((u64)bhi << 32);
-        if (lane_in(xm)) { seatbuf[rkm] = braw; olist[rkm] = (unsigned char)lane; }
-        if (lane_in(xs)) { seatbuf[rks] = braw; olist[rks] = (unsigned char)lane; }
-        wave_sync();
-        const u32 rs = (u32)lane - (u32)k;                        // this lane's seat number, if it is one
-        const u64 got = seatbuf[min(rs, 55u)];
-        const u32 w0 = *(const u32 *)olist;                        // (wave-uniform address: the indices of extras 0..3, a byte each)
-        const bool seat = rs < (u32)ne;
-        blo = seat ? (u32)got : blo; bhi = seat ? (u32)(got >> 32) : bhi;
-        const u64 em = ((1ull << nm) - 1ull) << k, ea = ((1ull << ne) - 1ull) << k;
-        N1 |= em; N2 |= ea & ~em;
-        const u64 b64 = (u64)blo | ((u64)bhi << 32);
-        u32 eb = (u32)((b64 >> (w0 & 63u)) & 1ull) | ((u32)((b64 >> ((w0 >> 8) & 63u)) & 1ull) << 1);
-        if (ne > 2) eb |= ((u32)((b64 >> ((w0 >> 16) & 63u)) & 1ull) << 2) | ((u32)((b64 >> ((w0 >> 24) & 63u)) & 1ull) << 3);
-        if (ne > 4) {
-            const u32 w1 = *(const u32 *)(olist + 4);
-            eb |= ((u32)((b64 >> (w1 & 63u)) & 1ull) << 4) | ((u32)((b64 >> ((w1 >> 8) & 63u)) & 1ull) << 5);
-            if (ne > 6) eb |= ((u32)((b64 >> ((w1 >> 16) & 63u)) & 1ull) << 6) | ((u32)((b64 >> ((w1 >> 24) & 63u)) & 1ull) << 7);
-        }
-        eb &= (1u << ne) - 1u;                                     // (slots beyond the last extra hold whatever an earlier evaluation left)
-        const u64 es64 = (u64)eb << k;
-        rlo = (blo & (u32)gprim) | (u32)es64; rhi = (bhi & (u32)(gprim >> 32)) | (u32)(es64 >> 32);
-        wave_sync();
-    } else {
-#endif
     // pass 1: seat the extra nodes (wave-uniform loops, a handful of trips): the seat's lane takes the vertex's mask
+    // (extra r is node k + r: the two lanes of u and v first, then the free lanes from s on.  The vertex's mask goes to the
+    //  seat's lane by v_readlane / v_writelane -- two vector instructions per half instead of a move and a select: the
+    //  kernel's time goes with its vector instructions first, scalar ones are the cheaper currency)
     int r = 0;
     for (u64 m = xm; m; m &= m - 1, ++r) {
-        const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
-        const u64 ho = rdlane64(myH, orig) & ~uv, pm = 1ull << pos;
-        const bool here = lane_in(pm);
-        blo = here ? (u32)ho : blo; bhi = here ? (u32)(ho >> 32) : bhi;
-        N1 |= pm;
+        const int orig = __ffsll((long long)m) - 1, pos = k + r;
+        const u64 ho = rdlane64(myH, orig) & ~uv;
+        blo = wrlane((u32)ho, pos, blo); bhi = wrlane((u32)(ho >> 32), pos, bhi);
+        N1 |= 1ull << pos;
     }
     for (u64 m = xs; m; m &= m - 1, ++r) {
-        const int orig = __ffsll((long long)m) - 1, pos = r < 2 ? k + r : s + r - 2;
-        const u64 ho = rdlane64(myH, orig) & ~uv, pm = 1ull << pos;
-        const bool here = lane_in(pm);
-        blo = here ? (u32)ho : blo; bhi = here ? (u32)(ho >> 32) : bhi;
-        N2 |= pm;
+        const int orig = __ffsll((long long)m) - 1, pos = k + r;
+        const u64 ho = rdlane64(myH, orig) & ~uv;
+        blo = wrlane((u32)ho, pos, blo); bhi = wrlane((u32)(ho >> 32), pos, bhi);
+        N2 |= 1ull << pos;
     }
     // pass 2: a child vertex shows up at its own index and at each of its extras (bit `orig` of the mask goes to bit `pos`;
     // both wave-uniform, so the half words involved are picked by scalar branches)
     rlo = blo & (u32)gprim; rhi = bhi & (u32)(gprim >> 32);
     r = 0;
-    for (u64 m = xm; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, r < 2 ? k + r : s + r - 2);
-    for (u64 m = xs; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, r < 2 ? k + r : s + r - 2);
-#if FCM_EVAL_V2
-    }
-#endif
+    for (u64 m = xm; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, k + r);
+    for (u64 m = xs; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, k + r);
     // children must not come earlier in the P*M*S* order: a P node may have any node as a child (G0), an M node the M and S
     // nodes (G1), an S node S nodes (G2), a lane that is no node nothing.  G0 > G1 > G2, so allowed = G2 | N1 & [P or M
     // node] | P & [P node], cut to the node lanes -- as lane masks turned into all-ones words and plain vector ANDs / ORs (no
@@ -700,7 +667,7 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
 // -1 if the bitmap disagrees with the static table.
 template <int MAXT>
 __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
-                                         u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
+                                         u64 *Hp, int lane, int tmax, fcm_acc_t<MAXT> (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     u64 myH = build_local(rows, stride32, Lv, s, lane);
@@ -724,7 +691,7 @@ __device__ __forceinline__ int flip_eval(const rsrc_t rows, u32 stride32, u32 Lv
 // the pair is not reciprocal in the bitmap.
 template <int MAXT>
 __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv, int k,
-                                        u32 coin, u64 *Hp, int lane, int tmax, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
+                                        u32 coin, u64 *Hp, int lane, int tmax, fcm_acc_t<MAXT> (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     const u64 myH = build_local(rows, stride32, Lv, s, lane);
@@ -742,7 +709,7 @@ __device__ __forceinline__ int del_eval(const rsrc_t rows, u32 stride32, u32 Lv,
 // the local set Lv (k vertices of K, then big, small), built by the caller.
 template <int MAXT>
 __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u32 dfrom, u32 dto, u64 *Hp, int lane,
-                                              int tmax, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
+                                              int tmax, fcm_acc_t<MAXT> (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard = nullptr)
 {
     const int s = k + 2;
     const bool act = lane < s;
@@ -1093,7 +1060,8 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
         in_bounds = ballot(cl && (c0 < mn || c0 > mx)) == 0ull;
     }
 
-    FcmGuard guard = {p.guard_limit, 0u};
+    // (deep kernels count in 64 bits: their bound guards 2^62 unless the test hook FCM_TEST_GUARD_LIMIT has lowered it)
+    FcmGuard guard = {(MAXT >= 7 && p.guard_limit == 0x7FFFFFFFull) ? (1ull << 62) : p.guard_limit, 0u};
     FCM_STAMP_DECL
     for (u64 done = 0; done < p.nprop; done += WAVE) {
         // ---- batch: lane s draws proposal `sampled + s` ------------------
@@ -1133,7 +1101,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
             const u32 coin = w1 & 1u;
             const u64 idx = rdlane64(l_idx, sidx);
 
-            int delta[MAXT + 1];
+            fcm_acc_t<MAXT> delta[MAXT + 1];
 #pragma unroll
             for (int q = 0; q <= MAXT; ++q) delta[q] = 0;
             EvScal es = {0, 0};
@@ -1390,7 +1358,7 @@ __global__ __launch_bounds__(WAVE, MINW) void fcm_step_kernel(const FcmStepParam
 #pragma unroll
                     for (int tq = 3; tq <= MAXT; ++tq) {
                         if (tq <= tmax) {
-                            const int sum = wave_sum_i32(delta[tq]);
+                            const fcm_acc_t<MAXT> sum = wave_sum_acc(delta[tq]);
                             if (lane == tq + 1) myd = (long long)sum;
                         }
                     }

@@ -36,18 +36,27 @@
 #define CQ_DEFER_WORDS 34u  // [0]: number of deferred pairs (u32), then up to 128 pair indices (u16)
 #define CQ_PSUM_WORDS 16u   // per wave: 16 x i32 count changes, then status, sum_k, spare x 2 ... (32 u32)
 #define CQ_MAXW 8u
+// (Hp + arc list of the waves 1, 2, 3 lie IN the wide evaluator's region: that evaluator runs on wave 0 only -- a simple move's
+//  exact run, the deferred pairs of a clique move -- while the other waves wait at a barrier; with W = 2 the workgroup then
+//  stays within the 10 KiB that let 16 of them share a CU.  Waves 4 .. 7 have theirs behind the clique arrays.)
+__host__ __device__ constexpr inline unsigned fcm_cq_alias_waves(int NW) { return fcm_lds_words(NW) / 128u < 3u ? fcm_lds_words(NW) / 128u : 3u; }
 __host__ __device__ constexpr inline unsigned fcm_cq_lds_words(int NW, unsigned chg_cap, unsigned W)
 {
     return fcm_mw_lds_words(NW, 1) + CQ_TABLE_WORDS + CQ_TALLY_WORDS + CQ_DIX_WORDS + CQ_DEFER_WORDS + W * CQ_PSUM_WORDS + fcm_clique_lds_words(chg_cap)
-           + (W - 1u) * 128u;
+           + (W - 1u > fcm_cq_alias_waves(NW) ? (W - 1u - fcm_cq_alias_waves(NW)) * 128u : 0u);
 }
 struct CqLds {
     u64 *mine, *wide, *tables;
     u32 *tly, *defer, *psum;
     unsigned char *dix;
     CliqueLds CL;
-    u64 *hp_more;     // Hp + arc list of wave w >= 1 at hp_more + (w - 1) * 128
+    u64 *hp_more;     // Hp + arc list of wave w >= 1: cq_hp(L, w)
+    unsigned alias;   // waves whose Hp lies in the wide evaluator's region
 };
+__device__ __forceinline__ u64 *cq_hp(const CqLds &L, u32 w)
+{
+    return w == 0u ? L.mine : (w <= L.alias ? L.wide + (size_t)(w - 1u) * 128u : L.hp_more + (size_t)(w - 1u - L.alias) * 128u);
+}
 // (everything whose place does not depend on the pair list's capacity comes first; W from the launch)
 __device__ __forceinline__ CqLds cq_carve(u64 *smem, int maxnw, u32 W, u32 chg_cap)
 {
@@ -62,6 +71,7 @@ __device__ __forceinline__ CqLds cq_carve(u64 *smem, int maxnw, u32 W, u32 chg_c
     u64 *cl = L.tables + CQ_TABLE_WORDS + CQ_TALLY_WORDS + CQ_DIX_WORDS + CQ_DEFER_WORDS + W * CQ_PSUM_WORDS;
     L.CL = clique_carve(cl);
     L.hp_more = cl + fcm_clique_lds_words(chg_cap);
+    L.alias = fcm_cq_alias_waves(maxnw);
     return L;
 }
 enum { CS_NCHG = 14, CS_NPAIRS, CS_STATUS, CS_ND };   // u32 words of the tally block the setup leaves its scalars in
@@ -252,7 +262,7 @@ __device__ __forceinline__ void cq_commit(u32 *rows, u32 stride32, const CliqueL
 // one pair on the fast evaluator: classes around (big, small) from the patched in-masks, one evaluation per changed
 // direction.  Returns false if the split graph of a needed direction does not fit 64 nodes.
 template <int MAXT>
-__device__ __forceinline__ bool cq_eval_pair(u64 myH, u64 *Hp, const CqPair &P, int tmax, int lane, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard, u32 &status)
+__device__ __forceinline__ bool cq_eval_pair(u64 myH, u64 *Hp, const CqPair &P, int tmax, int lane, fcm_acc_t<MAXT> (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard, u32 &status)
 {
     const int k = P.k, s = k + 2;
     const bool need_bs = P.o_bs != P.n_bs, need_sb = P.o_sb != P.n_sb;
@@ -281,7 +291,7 @@ __device__ __forceinline__ bool cq_eval_pair(u64 myH, u64 *Hp, const CqPair &P, 
 // pre-move bitmap.  Pairs the fast evaluator does not take are put on the deferred list (wave 0 takes them afterwards).
 template <int MAXT>
 __device__ __forceinline__ void cq_pairs(const MwChain &C, u64 *Hp, const CliqueLds CL, const unsigned char *dix, u32 *defer, int npairs, int n_d, u32 wv, u32 W,
-                                         int lane, int (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard, u32 &status, u32 &sum_k)
+                                         int lane, fcm_acc_t<MAXT> (&delta)[MAXT + 1], EvScal &es, FcmGuard *guard, u32 &status, u32 &sum_k)
 {
     const int tmax = MAXT;
     const rsrc_t rr = make_rows_rsrc(C.rows, C.rows_bytes);
@@ -344,7 +354,7 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
     u32 *stage = (u32 *)(smem + MW_SHARED_WORDS);          // record 0 of the ring: where a simple move's exact run leaves its record
     const CqLds L = cq_carve(smem, maxnw, W, p.chg_cap);
     u64 *mine_lds = L.mine;
-    u64 *Hp = wv == 0 ? mine_lds : L.hp_more + (size_t)(wv - 1u) * 128u;
+    u64 *Hp = cq_hp(L, wv);
     const u32 *T = (const u32 *)(mine_lds + 128);
     u64 *wide_lds = L.wide;
     const CliqueLds CL = L.CL;
@@ -596,7 +606,9 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
     }
 }
 
-// (W is a launch parameter: the block is W x 64 threads.  4 waves per SIMD: at most 128 VGPRs.)
+// (W is a launch parameter: the block is W x 64 threads.  4 waves per SIMD: at most 128 VGPRs.  A lean build in 64 VGPRs -- 8
+//  waves per SIMD, W = 2 at 4096 chains -- was built and measured in round 4: 6.6e7 proposals/s against the one-wave kernel's
+//  9.3e7 there; profiles/r04_cq_lean_dropped.diff)
 template <int MAXT>
 __global__ __launch_bounds__(CQ_MAXW * WAVE, 4) void fcm_step_cq_kernel(const FcmStepParams p)
 {
