@@ -101,6 +101,9 @@ SIGNATURES = {
     "fcm_sampler_apply_transition": (C.c_int, [vp, C.c_uint32, u32p, i32p, C.c_uint32, u64p, i32p, u64p, i32p]),
     "fcm_sampler_revert_transition": (C.c_int, [vp, C.c_uint32, u32p, i32p, C.c_uint32, u64p, C.c_int32, u64p, C.c_int32]),
     "fcm_sampler_single_edge_flip": (C.c_int, [vp, C.c_uint32, C.c_uint64, u32p, i32p, C.POINTER(C.c_uint32)]),
+    "fcm_sampler_apply_transitions": (C.c_int, [vp, u32p, i32p, u32p, C.c_uint32, u64p, i32p, u64p, i32p, i32p]),
+    "fcm_sampler_revert_transitions": (C.c_int, [vp, u32p, i32p, u32p, C.c_uint32, u64p, i32p, u64p, i32p, i32p]),
+    "fcm_sampler_single_edge_flips": (C.c_int, [vp, u64p, u32p, i32p, u32p]),
     "fcm_sampler_save_state": (C.c_int, [vp, C.c_char_p, C.c_uint64]),
     "fcm_sampler_load_state": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp), u64p]),
     "fcm_sampler_save_state_shard": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64]),

@@ -222,6 +222,60 @@ class MCMCSampler:
         self.info = {f: getattr(info, f) for f, _ in CSamplerInfo._fields_}
         self.n_chains = int(self.info["n_chains"])
 
+    # ---- the State API on every chain at once (fcm_sampler_apply_transitions / _revert_transitions / _single_edge_flips) ----
+    def _flat_transitions(self, transitions):
+        if len(transitions) != self.n_chains:
+            raise ValueError("one transition per chain: %d given, %d chains" % (len(transitions), self.n_chains))
+        m_cap = max(1, max(len(t.change_edges) for t in transitions))
+        e = np.zeros((self.n_chains, m_cap, 2), np.uint32)
+        a = np.zeros((self.n_chains, m_cap), np.int32)
+        m = np.zeros(self.n_chains, np.uint32)
+        for c, t in enumerate(transitions):
+            m[c] = len(t.change_edges)
+            for i, (ed, ad) in enumerate(t.change_edges):
+                e[c, i] = ed
+                a[c, i] = 1 if ad else 0
+        return e, a, m, m_cap
+
+    def apply_transitions(self, transitions):
+        """State::apply_transition (src/lib.rs:61-79) on every chain in one call: transitions[c] for chain c.  Returns
+        (counters, status): counters[c] = (pre, post) as the reference returns them, status[c] = 0 or the error code of a
+        chain whose transition was refused (that chain is unchanged)."""
+        e, a, m, m_cap = self._flat_transitions(transitions)
+        pre, post = np.zeros((self.n_chains, _ffi.MAX_COUNTS), np.uint64), np.zeros((self.n_chains, _ffi.MAX_COUNTS), np.uint64)
+        pl, ql, st = np.zeros(self.n_chains, np.int32), np.zeros(self.n_chains, np.int32), np.zeros(self.n_chains, np.int32)
+        check(lib().fcm_sampler_apply_transitions(self._h, e.ctypes.data_as(u32p), a.ctypes.data_as(i32p), m.ctypes.data_as(u32p), m_cap,
+                                                  pre.ctypes.data_as(u64p), pl.ctypes.data_as(i32p), post.ctypes.data_as(u64p), ql.ctypes.data_as(i32p),
+                                                  st.ctypes.data_as(i32p)))
+        return [([int(v) for v in pre[c, : pl[c]]], [int(v) for v in post[c, : ql[c]]]) for c in range(self.n_chains)], st
+
+    def revert_transitions(self, transitions, counters):
+        """State::revert_transition (src/lib.rs:81-95) on every chain in one call; counters[c] = the (pre, post) of chain c.
+        A chain whose transition is empty (Transition([])) is left alone."""
+        e, a, m, m_cap = self._flat_transitions(transitions)
+        pre, post = np.zeros((self.n_chains, _ffi.MAX_COUNTS), np.uint64), np.zeros((self.n_chains, _ffi.MAX_COUNTS), np.uint64)
+        pl, ql, st = np.zeros(self.n_chains, np.int32), np.zeros(self.n_chains, np.int32), np.zeros(self.n_chains, np.int32)
+        for c, (p_, q_) in enumerate(counters):
+            pre[c, : len(p_)] = p_
+            post[c, : len(q_)] = q_
+            pl[c], ql[c] = len(p_), len(q_)
+        check(lib().fcm_sampler_revert_transitions(self._h, e.ctypes.data_as(u32p), a.ctypes.data_as(i32p), m.ctypes.data_as(u32p), m_cap,
+                                                   pre.ctypes.data_as(u64p), pl.ctypes.data_as(i32p), post.ctypes.data_as(u64p), ql.ctypes.data_as(i32p),
+                                                   st.ctypes.data_as(i32p)))
+        return st
+
+    def single_edge_flips(self, xs):
+        """Transition::single_edge_flip (src/lib.rs:292-299) drawn on every chain's current graph: xs[c] = one uniform 64-bit
+        integer for chain c (the draw is DESIGN.md 3)."""
+        x = np.array([int(v) & (2 ** 64 - 1) for v in xs], np.uint64)
+        if len(x) != self.n_chains:
+            raise ValueError("one number per chain")
+        e = np.zeros((self.n_chains, 2, 2), np.uint32)
+        a = np.zeros((self.n_chains, 2), np.int32)
+        n = np.zeros(self.n_chains, np.uint32)
+        check(lib().fcm_sampler_single_edge_flips(self._h, x.ctypes.data_as(u64p), e.ctypes.data_as(u32p), a.ctypes.data_as(i32p), n.ctypes.data_as(u32p)))
+        return [Transition([((int(e[c, i, 0]), int(e[c, i, 1])), bool(a[c, i])) for i in range(int(n[c]))]) for c in range(self.n_chains)]
+
     def save_state(self, fname, sample_number=0):
         """io::save_state (src/io.rs:51-56): written to <fname>.tmp, then renamed."""
         check(lib().fcm_sampler_save_state(self._h, os.fsencode(fname), sample_number))

@@ -188,8 +188,154 @@ __global__ void fcm_set_edges_kernel(u32 *rows, u32 stride32, const u32 *__restr
 }
 
 // ---------------------------------------------------------------------------
+// The batched State API: State::apply_transition / revert_transition (src/lib.rs:61-95) on every chain of the batch in one
+// launch, one wave per chain -- what a search over many States at once needs (the reference's all_cxs runs 100 of them on OS
+// threads, src/bin/all_cxs.rs:33-86).  The transition changes the directions of one adjacent pair; (pre, post) are the
+// reference's vectors: flagser_count of the induced subgraph on N(a) cap N(b) + {a, b} before and after the set_edge calls
+// (a full count of that subgraph, not the through-the-edge counts of the step kernels): the local build of the step kernels,
+// then a walk over every ordered clique, lane = first vertex, 64-bit counts.
+// ---------------------------------------------------------------------------
+#define FCM_APPLY_MAXT 16   // cliques of up to 16 vertices: dimensions 0 .. 15, every entry a count vector of the ABI has
+__device__ __forceinline__ int apply_count_local(u64 myH, u64 *Hs, int s, int lane, u64 (&tot)[FCM_APPLY_MAXT + 1])
+{
+    u64 acc[FCM_APPLY_MAXT + 1];
+#pragma unroll
+    for (int q = 0; q <= FCM_APPLY_MAXT; ++q) acc[q] = 0ull;
+    u32 overflow = 0u;
+    wave_sync();
+    Hs[lane] = myH;
+    wave_sync();
+    if (lane < s) acc[1] = 1ull;                                         // the vertex itself: a clique of one
+    if (myH) visit<1, FCM_APPLY_MAXT, true, u64>(myH, Hs, FCM_APPLY_MAXT, +1, acc, overflow);
+    int len = 0;
+#pragma unroll
+    for (int q = 1; q <= FCM_APPLY_MAXT; ++q) {
+        tot[q] = (u64)wave_sum_i64((long long)acc[q]);
+        if (tot[q]) len = q;                                             // flagser_count stops at the last dimension present
+    }
+    return ballot(overflow != 0u) ? -1 : len;
+}
+
+__global__ __launch_bounds__(WAVE) void fcm_apply_batch_kernel(const FcmApplyParams p)
+{
+    __shared__ u64 Hs[WAVE];
+    const int lane = threadIdx.x;
+    const u32 c = blockIdx.x;
+    if (c >= p.nchains) return;
+    const u32 e = p.pair[c];
+    if (e == FCM_TR_SKIP) return;
+    const FcmEdgeEntry ent = p.etab[e];
+    const u32 big = rdlane(ent.big, 0), small = rdlane(ent.small, 0), off = rdlane(ent.nb_off, 0);
+    const int k = (int)rdlane(ent.k, 0), s = k + 2;
+    u32 *rows = p.rows + (size_t)c * p.rows_per_chain;
+    u64 *cnt = (u64 *)p.counts + (size_t)c * FCM_DEV_MAX_COUNTS;
+    u64 *st = (u64 *)p.stats + (size_t)c * FCM_DEV_NSTATS;
+    u32 *wbs = rows + (size_t)big * p.stride32 + (small >> 5), *wsb = rows + (size_t)small * p.stride32 + (big >> 5);
+    const u32 bit_s = 1u << (small & 31u), bit_b = 1u << (big & 31u);
+    const u32 op = p.ops[c], op_bs = op & 3u, op_sb = (op >> 2) & 3u;
+    const u32 vbs = *wbs, vsb = *wsb;
+    const u32 o_bs = (vbs & bit_s) ? 1u : 0u, o_sb = (vsb & bit_b) ? 1u : 0u;
+    const u32 n_bs = op_bs == 0u ? o_bs : (op_bs == 1u ? 1u : 0u), n_sb = op_sb == 0u ? o_sb : (op_sb == 1u ? 1u : 0u);
+    u32 status = FCM_TRS_OK;
+    if (!(o_bs | o_sb)) status = FCM_TRS_TABLE;                          // the table says adjacent, the bitmap says not
+    else if (!(n_bs | n_sb) || ((o_bs & o_sb) != (n_bs & n_sb))) status = FCM_TRS_UNSUPPORTED;   // pr(G) or the number of reciprocal pairs would change
+    u64 pre[FCM_APPLY_MAXT + 1], post[FCM_APPLY_MAXT + 1];
+    int lpre = 0, lpost = 0;
+    if (!p.revert) {
+        if (s > WAVE) { if (lane == 0) p.status[c] = FCM_TRS_HOST; return; }   // (left to the one-chain path)
+        if (status == FCM_TRS_OK) {
+            const rsrc_t rr = make_rows_rsrc(rows, p.rows_per_chain * 4ull);
+            const u32 Lv = load_list(p.nb, off, k, big, small, lane);
+            u64 myH = build_local(rr, p.stride32, Lv, s, lane);          // in-masks: lane j, bit i = L[i] -> L[j] (the same cliques, read backwards)
+            lpre = apply_count_local(myH, Hs, s, lane, pre);
+            // big = lane k, small = lane k + 1: big -> small is bit k of small's mask, small -> big bit k + 1 of big's
+            if (lane == k + 1) myH = n_bs ? (myH | (1ull << k)) : (myH & ~(1ull << k));
+            if (lane == k) myH = n_sb ? (myH | (1ull << (k + 1))) : (myH & ~(1ull << (k + 1)));
+            lpost = apply_count_local(myH, Hs, s, lane, post);
+            if (lpre < 0 || lpost < 0) status = FCM_TRS_DEEP;
+        }
+    } else {
+        lpre = (int)p.lens[2 * c]; lpost = (int)p.lens[2 * c + 1];
+#pragma unroll
+        for (int q = 1; q <= FCM_APPLY_MAXT; ++q) { pre[q] = p.pre[(size_t)c * FCM_DEV_MAX_COUNTS + q - 1]; post[q] = p.post[(size_t)c * FCM_DEV_MAX_COUNTS + q - 1]; }
+    }
+    // flag_count -= sub (asserting, :64-67 / :85-88), resized up to the other vector's length, += add (:72-77 / :89-94): apply
+    // subtracts pre and adds post, revert the other way round.  Lane d holds entry d.
+    const int nc = (int)p.ncounts;
+    const u64 len0 = st[FCM_STAT_COUNT_LEN_DEV];
+    u64 mine = lane < nc ? cnt[lane] : 0ull, subv = 0ull, addv = 0ull;
+    int lsub = p.revert ? lpost : lpre, ladd = p.revert ? lpre : lpost;
+#pragma unroll
+    for (int q = 1; q <= FCM_APPLY_MAXT; ++q) {
+        if (lane == q - 1) { subv = p.revert ? post[q] : pre[q]; addv = p.revert ? pre[q] : post[q]; }
+    }
+    const bool in_sub = lane < lsub && lane < nc && lane < (int)len0, in_add = lane < ladd && lane < nc;
+    if (status == FCM_TRS_OK && ballot(in_sub && mine < subv)) status = FCM_TRS_ASSERT;
+    if (status == FCM_TRS_OK) {
+        if (in_sub) mine -= subv;
+        if (in_add) mine += addv;
+        if (lane < nc) cnt[lane] = mine;
+        if (lane == 0) {
+            const u64 nl = (u64)(ladd < nc ? ladd : nc);
+            if (nl > len0) st[FCM_STAT_COUNT_LEN_DEV] = nl;              // flag_count.resize: never shrinks
+            if (n_bs != o_bs) *wbs = n_bs ? (vbs | bit_s) : (vbs & ~bit_s);
+            if (n_sb != o_sb) *wsb = n_sb ? (vsb | bit_b) : (vsb & ~bit_b);
+        }
+    }
+    if (!p.revert && lane < FCM_DEV_MAX_COUNTS) {
+        u64 a = 0ull, b = 0ull;
+#pragma unroll
+        for (int q = 1; q <= FCM_APPLY_MAXT; ++q) if (lane == q - 1) { a = status == FCM_TRS_OK || status == FCM_TRS_ASSERT ? pre[q] : 0ull; b = status == FCM_TRS_OK || status == FCM_TRS_ASSERT ? post[q] : 0ull; }
+        p.pre[(size_t)c * FCM_DEV_MAX_COUNTS + lane] = a;
+        p.post[(size_t)c * FCM_DEV_MAX_COUNTS + lane] = b;
+    }
+    if (lane == 0) {
+        if (!p.revert) { p.lens[2 * c] = (u32)(lpre > 0 ? lpre : 0); p.lens[2 * c + 1] = (u32)(lpost > 0 ? lpost : 0); }
+        p.status[c] = status;
+    }
+}
+
+// Transition::single_edge_flip (src/lib.rs:292-299) drawn on every chain at once: r = mulhi64(x, U + D) names a directed
+// edge; out = {pair id, from, to}, or FCM_TR_SKIP for the empty transition.  One thread per chain.
+__global__ void fcm_flip_draw_kernel(const FcmFlipDrawParams p)
+{
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.nchains) return;
+    u32 *o = p.out + 3 * (size_t)c;
+    o[0] = FCM_TR_SKIP; o[1] = 0u; o[2] = 0u;
+    const u64 M = (u64)p.U + p.D;
+    if (M == 0) return;
+    const u64 r = __umul64hi(p.x[c], M);
+    if (r >= p.U) return;                                                // the second direction of a reciprocal pair
+    const FcmEdgeEntry ent = p.etab[r];
+    const u32 *rows = p.rows + (size_t)c * p.rows_per_chain;
+    u32 bs, sb;
+    if (p.sparse) {
+        const u32 w = rows[(2 * r) >> 5];
+        bs = (w >> ((2 * r) & 31)) & 1u; sb = (w >> ((2 * r + 1) & 31)) & 1u;
+    } else {
+        bs = (rows[(size_t)ent.big * p.stride32 + (ent.small >> 5)] >> (ent.small & 31u)) & 1u;
+        sb = (rows[(size_t)ent.small * p.stride32 + (ent.big >> 5)] >> (ent.big & 31u)) & 1u;
+    }
+    if (bs == sb) { if (!bs) o[0] = 0xFFFFFFFEu; return; }               // reciprocal: empty transition; (absent from the bitmap: the host reports it)
+    o[0] = (u32)r; o[1] = bs ? ent.big : ent.small; o[2] = bs ? ent.small : ent.big;
+}
+
+// ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
+extern "C" int fcm_launch_apply_batch(const FcmApplyParams *p, void *stream)
+{
+    if (p->nchains == 0) return 0;
+    hipLaunchKernelGGL(fcm_apply_batch_kernel, dim3(p->nchains), dim3(WAVE), 0, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int fcm_launch_flip_draw(const FcmFlipDrawParams *p, void *stream)
+{
+    if (p->nchains == 0) return 0;
+    hipLaunchKernelGGL(fcm_flip_draw_kernel, dim3((p->nchains + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
 extern "C" int fcm_launch_gather_sub(const uint32_t *rows, uint32_t stride32, const uint32_t *list, uint32_t nl, uint32_t nlw, uint32_t *out, void *stream)
 {
     if (nl == 0) return 0;

@@ -5,6 +5,7 @@
 
 #define FCM_DEV_MAX_COUNTS 16
 #define FCM_DEV_NSTATS 18
+#define FCM_STAT_COUNT_LEN_DEV 6   // (= FCM_STAT_COUNT_LEN of include/fcm.h)
 #define FCM_MAX_SUB 32           // philox blocks (2 candidates each) tried for the single edge of a double-edge move
 #define FCM_LAUNCH_CHUNK (1u << 16)  // proposals per chain per kernel launch
 
@@ -72,9 +73,39 @@ struct FcmCountParams {
     uint64_t *xw_ws;           // second pass: [grid][FCM_XW_WORDS] workspaces (fcm_xwide.hpp)
 };
 
+// Batched State API (fcm_sampler_apply_transitions / _revert_transitions / _single_edge_flips): one transition per chain, all
+// chains in one launch.  A transition the kernel takes changes the directions of ONE adjacent pair (every transition the
+// reference's generators and search tools make) whose local set has at most 64 vertices; the host folds its change edges into
+// `ops` (per direction: keep / set / clear) and runs the rest through the one-chain path.
+#define FCM_TR_SKIP 0xFFFFFFFFu      // pair[c]: nothing for the kernel to do on this chain
+enum { FCM_TRS_OK = 0, FCM_TRS_HOST = 1, FCM_TRS_ASSERT = 2, FCM_TRS_UNSUPPORTED = 3, FCM_TRS_DEEP = 4, FCM_TRS_TABLE = 5 };
+struct FcmApplyParams {
+    const FcmEdgeEntry *etab;
+    const uint32_t *nb;
+    uint32_t *rows;
+    uint64_t *counts, *stats;
+    const uint32_t *pair;      // [n_chains] etab index of the transition's pair, or FCM_TR_SKIP
+    const uint32_t *ops;       // [n_chains] bits 0-1: big -> small (0 keep, 1 set, 2 clear), bits 2-3: small -> big
+    uint64_t *pre, *post;      // [n_chains][FCM_DEV_MAX_COUNTS]: apply writes them; revert reads them
+    uint32_t *lens;            // [n_chains][2] pre_len, post_len (apply writes, revert reads)
+    uint32_t *status;          // [n_chains] FCM_TRS_*
+    uint64_t rows_per_chain;
+    uint32_t stride32, nchains, ncounts, revert;
+};
+struct FcmFlipDrawParams {
+    const FcmEdgeEntry *etab;
+    const uint32_t *rows;
+    const uint64_t *x;         // [n_chains] one uniform 64-bit number per chain
+    uint32_t *out;             // [n_chains][3]: pair id (FCM_TR_SKIP: empty transition), from, to
+    uint64_t rows_per_chain;
+    uint32_t stride32, nchains, U, D, sparse;
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int fcm_launch_apply_batch(const FcmApplyParams *p, void *stream);
+int fcm_launch_flip_draw(const FcmFlipDrawParams *p, void *stream);
 // launchers implemented in fcm_kernels.hip; `stream` is a hipStream_t
 int fcm_launch_step(const FcmStepParams *p, int tmax, int clique, void *stream);
 int fcm_launch_count(const FcmCountParams *p, void *stream);

@@ -704,6 +704,7 @@ struct fcm_sampler {
     bool h_tables = false;
     DevBuf d_tr_list, d_tr_out, d_tr_chg;   // scratch of that API
     size_t tr_list_cap = 0, tr_out_cap = 0, tr_chg_cap = 0;
+    DevBuf d_bt_pair, d_bt_ops, d_bt_pre, d_bt_post, d_bt_lens, d_bt_status, d_bt_x, d_bt_out;   // the batched State API (one transition per chain), allocated on its first use
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1647,6 +1648,158 @@ try {
     if ((rc = update_counts(s, chain, post, post_len, pre, pre_len))) return rc;   // :85-94
     if ((rc = set_edges_on_device(s, chain, edges, add, n, true))) return rc;
     return commit_slots(s, chain, plan);
+} FCM_CATCH
+
+// ---------------------------------------------------------------------------
+// The batched State API: one transition per chain, every chain in one launch (fcm_apply_batch_kernel, fcm_count.hip).
+// ---------------------------------------------------------------------------
+static int ensure_batch_buffers(fcm_sampler *s)
+{
+    if (s->d_bt_pair.p) return FCM_OK;
+    const size_t C = s->params.nchains;
+    int rc;
+    if ((rc = s->d_bt_pair.alloc(C * 4)) || (rc = s->d_bt_ops.alloc(C * 4)) || (rc = s->d_bt_pre.alloc(C * FCM_MAX_COUNTS * 8)) || (rc = s->d_bt_post.alloc(C * FCM_MAX_COUNTS * 8))
+        || (rc = s->d_bt_lens.alloc(C * 8)) || (rc = s->d_bt_status.alloc(C * 4)) || (rc = s->d_bt_x.alloc(C * 8)) || (rc = s->d_bt_out.alloc(C * 12))) return rc;
+    return FCM_OK;
+}
+
+// The change edges of one transition folded into what the kernel takes: the one adjacent pair they lie on and, per direction,
+// keep / set / clear (set_edge calls in order: the last one on a direction decides; `invert`: a revert sets !add).  Returns
+// 0 = folded, 1 = the edges lie on several pairs (one-chain path), or a failing status (out of range, not adjacent).
+static int fold_transition(const fcm_sampler *s, const fcm_node *edges, const int32_t *add, uint32_t n, bool invert, uint32_t &pair, uint32_t &ops)
+{
+    pair = FCM_TR_SKIP; ops = 0u;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t a = edges[2 * i], b = edges[2 * i + 1];
+        if (a >= s->n || b >= s->n || a == b) return -FCM_ERR_INVALID;
+        const int64_t e = pair_index(s, a, b);
+        if (e < 0) return -FCM_ERR_PANIC;                              // the reference indexes edge_neighborhood with it (src/lib.rs:104)
+        if (pair != FCM_TR_SKIP && pair != (uint32_t)e) return 1;
+        pair = (uint32_t)e;
+        const uint32_t code = ((add[i] != 0) != invert) ? 1u : 2u, sh = a > b ? 0u : 2u;   // a > b: the direction big -> small
+        ops = (ops & ~(3u << sh)) | (code << sh);
+    }
+    return 0;
+}
+
+static int batch_transitions(fcm_sampler *s, const fcm_node *edges, const int32_t *add, const uint32_t *m, uint32_t m_cap, bool revert,
+                             uint64_t *pre, int32_t *pre_len, uint64_t *post, int32_t *post_len, int32_t *status)
+{
+    if (!s || !m || !pre || !pre_len || !post || !post_len) return fail(FCM_ERR_INVALID, "NULL argument");
+    const uint32_t C = s->params.nchains;
+    int rc = fcm_sampler_sync(s);
+    if (rc) return rc;
+    if ((rc = ensure_batch_buffers(s))) return rc;
+    std::vector<uint32_t> pair(C, FCM_TR_SKIP), ops(C, 0u), lens(2 * (size_t)C, 0u), dst(C, 0u);
+    std::vector<int32_t> code(C, FCM_OK);
+    std::vector<uint8_t> host_path(C, 0);
+    bool any_kernel = false;
+    for (uint32_t c = 0; c < C; ++c) {
+        if (m[c] > m_cap || (m[c] && (!edges || !add))) return fail(FCM_ERR_INVALID, "chain %u: %u change edges, room for %u", c, m[c], m_cap);
+        if (revert && (pre_len[c] < 0 || post_len[c] < 0 || pre_len[c] > FCM_MAX_COUNTS || post_len[c] > FCM_MAX_COUNTS)) return fail(FCM_ERR_INVALID, "chain %u: bad (pre, post)", c);
+        const int f = fold_transition(s, edges + (size_t)c * m_cap * 2, add + (size_t)c * m_cap, m[c], revert, pair[c], ops[c]);
+        if (f < 0) { code[c] = -f; pair[c] = FCM_TR_SKIP; continue; }
+        if (f == 1 || s->sparse) { host_path[c] = 1; pair[c] = FCM_TR_SKIP; continue; }
+        if (pair[c] != FCM_TR_SKIP) any_kernel = true;
+        if (revert) { lens[2 * (size_t)c] = (uint32_t)pre_len[c]; lens[2 * (size_t)c + 1] = (uint32_t)post_len[c]; }
+    }
+    if (any_kernel) {
+        HIP_TRY(hipMemcpyAsync(s->d_bt_pair.p, pair.data(), (size_t)C * 4, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_bt_ops.p, ops.data(), (size_t)C * 4, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemsetAsync(s->d_bt_status.p, 0, (size_t)C * 4, s->stream));
+        if (revert) {
+            HIP_TRY(hipMemcpyAsync(s->d_bt_lens.p, lens.data(), (size_t)C * 8, hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipMemcpyAsync(s->d_bt_pre.p, pre, (size_t)C * FCM_MAX_COUNTS * 8, hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipMemcpyAsync(s->d_bt_post.p, post, (size_t)C * FCM_MAX_COUNTS * 8, hipMemcpyHostToDevice, s->stream));
+        }
+        FcmApplyParams ap;
+        memset(&ap, 0, sizeof ap);
+        ap.etab = s->params.etab; ap.nb = s->params.nb; ap.rows = s->params.rows; ap.counts = s->params.counts; ap.stats = s->params.stats;
+        ap.pair = s->d_bt_pair.as<uint32_t>(); ap.ops = s->d_bt_ops.as<uint32_t>(); ap.pre = s->d_bt_pre.as<uint64_t>(); ap.post = s->d_bt_post.as<uint64_t>();
+        ap.lens = s->d_bt_lens.as<uint32_t>(); ap.status = s->d_bt_status.as<uint32_t>();
+        ap.rows_per_chain = s->params.rows_per_chain; ap.stride32 = s->params.stride32; ap.nchains = C; ap.ncounts = (uint32_t)s->params.ncounts; ap.revert = revert ? 1u : 0u;
+        int lrc = fcm_launch_apply_batch(&ap, s->stream);
+        if (lrc) return fail(FCM_ERR_HIP, "batched transition launch failed: %s", hipGetErrorString((hipError_t)lrc));
+        HIP_TRY(hipMemcpyAsync(dst.data(), s->d_bt_status.p, (size_t)C * 4, hipMemcpyDeviceToHost, s->stream));
+        if (!revert) {
+            HIP_TRY(hipMemcpyAsync(lens.data(), s->d_bt_lens.p, (size_t)C * 8, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(pre, s->d_bt_pre.p, (size_t)C * FCM_MAX_COUNTS * 8, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(post, s->d_bt_post.p, (size_t)C * FCM_MAX_COUNTS * 8, hipMemcpyDeviceToHost, s->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    int first = FCM_OK;
+    for (uint32_t c = 0; c < C; ++c) {
+        uint64_t *pc = pre + (size_t)c * FCM_MAX_COUNTS, *qc = post + (size_t)c * FCM_MAX_COUNTS;
+        if (code[c] == FCM_OK && pair[c] != FCM_TR_SKIP) {
+            switch (dst[c]) {
+            case FCM_TRS_OK: break;
+            case FCM_TRS_HOST: host_path[c] = 1; break;                // a local set beyond 64 vertices
+            case FCM_TRS_ASSERT: code[c] = FCM_ERR_PANIC; fail(FCM_ERR_PANIC, "chain %u: the reference's assert!(*s >= *p) fires (src/lib.rs:65,86)", c); break;
+            case FCM_TRS_UNSUPPORTED: code[c] = FCM_ERR_UNSUPPORTED; fail(FCM_ERR_UNSUPPORTED, "chain %u: the transition changes the number of reciprocal pairs or leaves the pair without an edge", c); break;
+            case FCM_TRS_DEEP: code[c] = FCM_ERR_UNSUPPORTED; fail(FCM_ERR_UNSUPPORTED, "chain %u: simplices beyond dimension %d in the neighbourhood", c, FCM_MAX_COUNTS - 1); break;
+            default: code[c] = FCM_ERR_INTERNAL; fail(FCM_ERR_INTERNAL, "chain %u: the pair is adjacent in the table and absent from the bitmap", c); break;
+            }
+            if (!revert && dst[c] != FCM_TRS_HOST) { pre_len[c] = (int32_t)lens[2 * (size_t)c]; post_len[c] = (int32_t)lens[2 * (size_t)c + 1]; }
+        } else if (code[c] == FCM_OK && !host_path[c] && !revert) {    // the empty transition: both vectors empty (the subgraph on no vertices)
+            for (int d = 0; d < FCM_MAX_COUNTS; ++d) pc[d] = qc[d] = 0;
+            pre_len[c] = post_len[c] = 0;
+        }
+        if (host_path[c]) {                                            // several pairs, a wide neighbourhood, or the sparse state: the one-chain path
+            const fcm_node *ec = edges + (size_t)c * m_cap * 2;
+            const int32_t *ac = add + (size_t)c * m_cap;
+            code[c] = revert ? fcm_sampler_revert_transition(s, c, ec, ac, m[c], pc, pre_len[c], qc, post_len[c])
+                             : fcm_sampler_apply_transition(s, c, ec, ac, m[c], pc, &pre_len[c], qc, &post_len[c]);
+        }
+        if (code[c] == FCM_ERR_INVALID) fail(FCM_ERR_INVALID, "chain %u: a change edge is out of range or a loop", c);
+        if (code[c] == FCM_ERR_PANIC && pair[c] == FCM_TR_SKIP && !host_path[c]) fail(FCM_ERR_PANIC, "chain %u: a change edge is not on an adjacent pair of pr(G) (src/lib.rs:104)", c);
+        if (status) status[c] = code[c];
+        if (first == FCM_OK && code[c] != FCM_OK) first = code[c];
+    }
+    return status ? FCM_OK : first;
+}
+
+extern "C" int fcm_sampler_apply_transitions(fcm_sampler *s, const fcm_node *edges, const int32_t *add, const uint32_t *m, uint32_t m_cap,
+                                             uint64_t *pre, int32_t *pre_len, uint64_t *post, int32_t *post_len, int32_t *status)
+try {
+    return batch_transitions(s, edges, add, m, m_cap, false, pre, pre_len, post, post_len, status);
+} FCM_CATCH
+
+extern "C" int fcm_sampler_revert_transitions(fcm_sampler *s, const fcm_node *edges, const int32_t *add, const uint32_t *m, uint32_t m_cap,
+                                              const uint64_t *pre, const int32_t *pre_len, const uint64_t *post, const int32_t *post_len, int32_t *status)
+try {
+    return batch_transitions(s, edges, add, m, m_cap, true, (uint64_t *)pre, (int32_t *)pre_len, (uint64_t *)post, (int32_t *)post_len, status);
+} FCM_CATCH
+
+// Transition::single_edge_flip on every chain at once: x[c] = one uniform 64-bit number per chain.
+extern "C" int fcm_sampler_single_edge_flips(fcm_sampler *s, const uint64_t *x, fcm_node *edges /* [n_chains][2][2] */, int32_t *add /* [n_chains][2] */, uint32_t *n /* [n_chains] */)
+try {
+    if (!s || !x || !edges || !add || !n) return fail(FCM_ERR_INVALID, "NULL argument");
+    const uint32_t C = s->params.nchains;
+    int rc = fcm_sampler_sync(s);
+    if (rc) return rc;
+    if ((rc = ensure_batch_buffers(s))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_bt_x.p, x, (size_t)C * 8, hipMemcpyHostToDevice, s->stream));
+    FcmFlipDrawParams fp;
+    memset(&fp, 0, sizeof fp);
+    fp.etab = s->params.etab; fp.rows = s->params.rows; fp.x = s->d_bt_x.as<uint64_t>(); fp.out = s->d_bt_out.as<uint32_t>();
+    fp.rows_per_chain = s->params.rows_per_chain; fp.stride32 = s->params.stride32; fp.nchains = C; fp.U = s->params.U; fp.D = s->params.D; fp.sparse = s->sparse ? 1u : 0u;
+    int lrc = fcm_launch_flip_draw(&fp, s->stream);
+    if (lrc) return fail(FCM_ERR_HIP, "flip draw launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    std::vector<uint32_t> out(3 * (size_t)C);
+    HIP_TRY(hipMemcpyAsync(out.data(), s->d_bt_out.p, out.size() * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (uint32_t c = 0; c < C; ++c) {
+        if (out[3 * (size_t)c] == 0xFFFFFFFEu) return fail(FCM_ERR_INTERNAL, "chain %u: a pair is adjacent in the table and absent from the bitmap", c);
+        n[c] = 0;
+        if (out[3 * (size_t)c] == FCM_TR_SKIP) continue;                // empty transition (:297-298)
+        const uint32_t from = out[3 * (size_t)c + 1], to = out[3 * (size_t)c + 2];
+        fcm_node *e = edges + 4 * (size_t)c;
+        e[0] = from; e[1] = to; add[2 * (size_t)c] = 0;                 // ([from,to], false), ([to,from], true) (:295)
+        e[2] = to; e[3] = from; add[2 * (size_t)c + 1] = 1;
+        n[c] = 2;
+    }
+    return FCM_OK;
 } FCM_CATCH
 
 // Transition::single_edge_flip (src/lib.rs:292-299) on the chain's current graph.  The reference draws a directed edge

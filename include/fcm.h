@@ -262,6 +262,26 @@ int fcm_sampler_single_edge_flip(fcm_sampler *s, uint32_t chain, uint64_t x, fcm
                                  uint32_t *n);
 
 /* ------------------------------------------------------------------------ */
+/* The same, one transition per chain, every chain of the handle in one launch -- what a search that drives many States at   */
+/* once needs (the reference's all_cxs runs 100 of them on OS threads, src/bin/all_cxs.rs:33-86).  Chain c's transition is   */
+/* m[c] <= m_cap change edges at edges[c][0 .. m[c])[2] / add[c][..]; m[c] = 0 is the empty transition ((pre, post) = ([],  */
+/* [])).  pre / post: [n_chains][FCM_MAX_COUNTS], *_len: [n_chains].  A transition whose change edges lie on ONE adjacent    */
+/* pair with a local set of at most 64 vertices (every transition of the reference's generators and search tools) is counted  */
+/* and applied on the GPU by one wave per chain; others go through the one-chain call above, chain by chain.  status (may be  */
+/* NULL): [n_chains] FCM_OK or the code the one-chain call would have returned for that chain -- a failing chain is left       */
+/* unchanged, the others are applied, and the call returns FCM_OK; with status == NULL the call returns the first failing      */
+/* chain's code (the other chains are applied all the same).                                                                   */
+/* ------------------------------------------------------------------------ */
+int fcm_sampler_apply_transitions(fcm_sampler *s, const fcm_node *edges /* [n_chains][m_cap][2] */, const int32_t *add /* [n_chains][m_cap] */,
+                                  const uint32_t *m /* [n_chains] */, uint32_t m_cap, uint64_t *pre, int32_t *pre_len, uint64_t *post,
+                                  int32_t *post_len, int32_t *status);
+int fcm_sampler_revert_transitions(fcm_sampler *s, const fcm_node *edges, const int32_t *add, const uint32_t *m, uint32_t m_cap,
+                                   const uint64_t *pre, const int32_t *pre_len, const uint64_t *post, const int32_t *post_len, int32_t *status);
+/* Transition::single_edge_flip drawn on every chain at once: x[c] = one uniform 64-bit number for chain c; edges:           */
+/* [n_chains][2][2], add: [n_chains][2], n: [n_chains] (0 or 2), laid out for fcm_sampler_apply_transitions with m_cap = 2.  */
+int fcm_sampler_single_edge_flips(fcm_sampler *s, const uint64_t *x, fcm_node *edges, int32_t *add, uint32_t *n);
+
+/* ------------------------------------------------------------------------ */
 /* Checkpoint / resume: the role of io::save_state / io::load_state           */
 /* (src/io.rs:51-62; called at src/bin/sample.rs:114-115,129-132,146).  Own    */
 /* format (the reference's is bincode of serde-derived types that live in the */

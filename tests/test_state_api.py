@@ -162,3 +162,93 @@ def test_transitions_the_api_refuses_change_nothing(fcm, oracle):
         sg.revert_transition(fcm.Transition([((f, t_), False), ((t_, f), True)]), ([n, 10 ** 9], [n, 10 ** 9, 10 ** 9]))
     assert ei.value.code == fcm._ffi.ERR_PANIC
     assert before == (sg.flag_count, s.edges(0).tolist(), s.double_slots(0).tolist())
+
+
+def test_greedy_search_on_256_chains_at_once(fcm, oracle):
+    """the loop of src/bin/seo_search_counterexample.rs:51-89 -- draw a flip, apply it, keep it only if
+    the number of 2-simplices grew, else revert -- on 256 chains of one handle in lockstep through the batched calls
+    (fcm_sampler_single_edge_flips / _apply_transitions / _revert_transitions: one launch per call for all chains), against
+    256 oracle States driven one by one.  Every (pre, post), every draw and every final state equal."""
+    import time
+    n, C, iters = 60, 256, 40
+    e = fcm.graphs.seoify(fcm.graphs.random_with_p(n, 0.3, seed=2), seed=2)
+    gg, go, bg, bo = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, bg, n_chains=C, seed=5)
+    sos = [oracle.State(go) for _ in range(C)]
+    ue = sos[0].undirected_edges()
+    U = len(ue)
+    rng = np.random.default_rng(17)
+    kept = np.zeros(C, np.int64)
+    t_gpu = 0.0
+    for it in range(iters):
+        xs = [int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2)) for _ in range(C)]
+        t0 = time.perf_counter()
+        ts = s.single_edge_flips(xs)
+        counters, st = s.apply_transitions(ts)
+        t_gpu += time.perf_counter() - t0
+        assert (st == 0).all()
+        back, back_counters = [], []
+        for c in range(C):
+            r = (xs[c] * U) >> 64                                         # the same draw on the oracle's graph (no reciprocal pairs: D = 0)
+            big, small = int(ue[r][0]), int(ue[r][1])
+            f, t_ = (big, small) if sos[c].graph().has_edge(big, small) else (small, big)
+            assert ts[c].change_edges == [((f, t_), False), ((t_, f), True)], (it, c)
+            pre, post = counters[c]
+            assert (pre, post) == sos[c].apply_transition(ts[c].change_edges), (it, c)
+            accept = not (len(post) < len(pre)) and not (len(post) > 2 and len(pre) > 2 and post[2] <= pre[2])
+            kept[c] += accept
+            if accept:
+                back.append(fcm.Transition([])); back_counters.append(([], []))
+            else:
+                sos[c].revert_transition(ts[c].change_edges, (pre, post))
+                back.append(ts[c]); back_counters.append((pre, post))
+        t0 = time.perf_counter()
+        st = s.revert_transitions(back, back_counters)
+        t_gpu += time.perf_counter() - t0
+        assert (st == 0).all()
+    fcs = s.flag_counts(with_len=True)
+    for c in range(C):
+        assert [int(v) for v in fcs[0][c, : fcs[1][c]]] == sos[c].flag_count, c
+    for c in (0, 1, 100, 255):
+        assert (s.edges(c) == sos[c].graph_edges()).all()
+    assert kept.min() >= 1 and kept.max() < iters and len(set(kept.tolist())) > 3        # the chains went different ways
+    print("batched State API: %d chains x %d iterations, %.1f us per transition (draw + apply + revert calls)" % (C, iters, 1e6 * t_gpu / (C * iters)))
+    # the sampler steps on from the states the search left
+    s.step(300)
+    assert (s.stats()["status"] == 0).all()
+    for c in (3, 200):
+        assert s.graph(c).flagser_count() == s.flag_count(c)[: len(s.graph(c).flagser_count())]
+
+
+def test_batched_transitions_refuse_per_chain_and_fall_back(fcm, oracle):
+    """Per-chain outcomes of one batched call: an empty transition, a flip, a transition on two pairs (taken by the one-chain
+    path), one the API refuses (the pair's only edge goes) and one off pr(G) (the reference's HashMap panic) -- the refused
+    chains are left as they were, the others are applied, and each chain's code says which."""
+    n = 40
+    e = fcm.graphs.random_with_p(n, 0.25, seed=4)
+    gg, go, bg, bo = setup_pair(fcm, oracle, n, e)
+    s = fcm.MCMCSampler(gg, bg, n_chains=5, seed=1)
+    so = [oracle.State(go) for _ in range(5)]
+    und = {(int(a), int(b)) for a, b in so[0].undirected_edges()}
+    cur = {(int(a), int(b)) for a, b in e}
+    singles = [(a, b) for a, b in sorted(und) if ((a, b) in cur) != ((b, a) in cur)]
+    def flip(p):
+        a, b = p
+        f, t_ = (a, b) if (a, b) in cur else (b, a)
+        return [((f, t_), False), ((t_, f), True)]
+    non_adjacent = next((a, b) for a in range(n) for b in range(a) if (a, b) not in und)
+    two_pairs = flip(singles[0]) + flip(singles[5])
+    only_edge_goes = [flip(singles[1])[0]]
+    ts = [fcm.Transition([]), fcm.Transition(flip(singles[2])), fcm.Transition(two_pairs), fcm.Transition(only_edge_goes), fcm.Transition([(non_adjacent, True)])]
+    before = [(s.flag_count(c), s.edges(c).tolist()) for c in range(5)]
+    counters, st = s.apply_transitions(ts)
+    assert st.tolist() == [0, 0, 0, fcm._ffi.ERR_UNSUPPORTED, fcm._ffi.ERR_PANIC]
+    for c in (0, 1, 2):
+        assert counters[c] == so[c].apply_transition(ts[c].change_edges), c
+        assert s.flag_count(c) == so[c].flag_count and (s.edges(c) == so[c].graph_edges()).all()
+    for c in (3, 4):
+        assert (s.flag_count(c), s.edges(c).tolist()) == before[c]
+    st = s.revert_transitions([ts[0], ts[1], ts[2], fcm.Transition([]), fcm.Transition([])], [counters[0], counters[1], counters[2], ([], []), ([], [])])
+    assert (st == 0).all()
+    for c in range(5):
+        assert (s.flag_count(c), s.edges(c).tolist()) == before[c], c
