@@ -59,7 +59,7 @@ def algorithmic_bytes(d, n, clique_pairs=None):
     return rows_simple * W + 64 * int(d["n_flip"]) + 128 * int(d["n_dmove"]) + 64 * nchg + 16 * int(d["n_empty"])
 
 
-def needed_bytes(d, n, mean_k):
+def needed_bytes(d, n, mean_k, clique_pairs=None):
     """Bytes the kernels actually have to move when rows are longer than one 128-B line (n > 1024): a local
     build reads, of each of its k+2 rows, only the lines that hold the k+2 bit positions it tests.
     Expected distinct lines per row for k+2 uniform positions among nl lines: nl * (1 - (1 - 1/nl)^(k+2)).
@@ -69,7 +69,11 @@ def needed_bytes(d, n, mean_k):
     s = mean_k + 2.0
     lines = nl * (1.0 - (1.0 - 1.0 / nl) ** s)
     evals = int(d["n_flip"]) + 2 * int(d["n_dmove"]) + int(d.get("n_changes", 0))
-    return evals * (s * lines * 128.0 + 16.0 + 4.0 * mean_k + 64.0) + 16.0 * int(d["n_empty"])
+    shared = 0.0
+    if clique_pairs is not None and int(d.get("n_changes", 0)) > 0:   # a clique move: one build per changed PAIR, the clique's own rows once per move
+        pairs, shared = clique_pairs
+        evals = int(d["n_flip"]) + 2 * int(d["n_dmove"]) + pairs
+    return evals * (s * lines * 128.0 + 16.0 + 4.0 * mean_k + 64.0) - shared * lines * 128.0 + 16.0 * int(d["n_empty"])
 
 
 def sparse_bytes(d, mean_k):
@@ -353,7 +357,8 @@ def main():
         clique = weights[2] > 0 or weights[3] > 0
         # clique moves: rows that are read once are charged once (FCM_STAT_PAIRS, FCM_STAT_SHARED_ROWS)
         clique_bytes = algorithmic_bytes(d, n, (float(d["n_pairs"]), float(d["n_shared_rows"]))) / args.steps if clique else None
-        abytes = sparse_bytes(d, mean_k) / args.steps if sparse else (needed_bytes(d, n, mean_k) / args.steps if long_rows else (clique_bytes if clique else survey_bytes))
+        cpairs = (float(d["n_pairs"]), float(d["n_shared_rows"])) if clique else None
+        abytes = sparse_bytes(d, mean_k) / args.steps if sparse else (needed_bytes(d, n, mean_k, cpairs) / args.steps if long_rows else (clique_bytes if clique else survey_bytes))
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         this_lib = lib_sha16(fcm.LIB_PATH)
         traffic, traffic_source = load_traffic(args.config, args.chains, args.proposals, args.moves, this_lib, sparse)

@@ -350,7 +350,21 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
             cbs.S = csb.S = inB & inS & nbm;
             cbs.M = inS & outB & nbm;
             csb.M = inB & outS & nbm;
-            if ((!need_bs || extras_fit(cbs, s)) && (!need_sb || extras_fit(csb, s))) {
+            bool merged = false;
+            if constexpr (MAXT <= 6) {   // both directions change: the pair is flipped -- one signed evaluation for the two (eval_flip_merged)
+                if (tmax == MAXT && need_bs && need_sb && (o_bs ^ o_sb) != 0u) {
+                    const u64 MA = o_bs ? cbs.M : csb.M, MB = o_bs ? csb.M : cbs.M;
+                    merged = flip_merged_fits(cbs.P, MA, MB, cbs.S, k) && eval_flip_merged<MAXT>(myH, Hp, cbs.P, MA, MB, cbs.S, k, lane, delta, es);
+                }
+            }
+            if (merged) {
+                if (lane == 0) {
+                    *wbs = n_bs ? (vbs | bit_s) : (vbs & ~bit_s);
+                    *wsb = n_sb ? (vsb | bit_b) : (vsb & ~bit_b);
+                }
+                wave_sync();
+                done = true;
+            } else if ((!need_bs || extras_fit(cbs, s)) && (!need_sb || extras_fit(csb, s))) {
                 if (need_bs) eval_nodes<MAXT>(myH, Hp, cbs, k, tmax, n_bs ? +1 : -1, lane, delta, es, nullptr, nullptr, guard);
                 if constexpr (MAXT >= 7) {   // the bound on the 32-bit counts was passed: this direction on the wide path (64-bit counts)
                     if (need_bs && guard && guard->tripped) {

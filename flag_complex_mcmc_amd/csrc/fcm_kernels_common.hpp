@@ -656,6 +656,141 @@ __device__ __forceinline__ void eval_nodes(u64 myH, u64 *Hp, const Cls &c, int k
     wave_sync();
 }
 
+// ---------------------------------------------------------------------------
+// A flip as ONE evaluation (round 4).  Reversing u->v subtracts the simplices through u->v and adds those through v->u.
+// Around the pair the two share their P class (w->u, w->v) and their S class (u->w, v->w); only the middle differs: MA =
+// {u->w, w->v} before, MB = {v->w, w->u} after.  A clique with no middle node is counted by both evaluations and cancels.
+// So ONE split graph carries both middles -- no arc between an MA and an MB node -- and every clique is weighted by what it
+// holds: -1 with an MA node, +1 with an MB node, 0 with neither.  A prefix of P nodes only is "undetermined" (sg = 0) until
+// a middle node joins it; S children of an undetermined prefix lead nowhere (no middle can follow an S node) and are neither
+// listed as arcs nor walked.  One seating, one scan, one arc list -- 70 arcs on the headline graph where the two evaluations
+// list 118 -- and the P/S-only cliques, most of the count, are never enumerated.  Weights at a level: children in MB count
+// +1, in MA -1, in S the prefix's sign (0 while undetermined), in P 0: three masked popcounts.
+// cls[x]: the sign a node brings (-1 MA, +1 MB, 0 P; S nodes hold 2 and are never asked).
+// ---------------------------------------------------------------------------
+#define FCM_MERGED_CAP 224   // arcs the list takes here: the last 64 bytes of its region hold cls[]
+template <int T, int MAXT>
+__device__ __forceinline__ void visit_sg(u64 cand, int sg, const u64 *Hp, const signed char *cls, u64 NA, u64 NB, u64 NS, int (&delta)[MAXT + 1])
+{
+    if constexpr (T < MAXT) {
+        const u32 clo = (u32)cand, chi = (u32)(cand >> 32);
+        const int b = __popc(clo & (u32)NB) + __popc(chi & (u32)(NB >> 32));
+        const int a = __popc(clo & (u32)NA) + __popc(chi & (u32)(NA >> 32));
+        const int s = __popc(clo & (u32)NS) + __popc(chi & (u32)(NS >> 32));
+        delta[T + 1] += b - a + sg * s;
+        if constexpr (T + 2 <= MAXT) {
+            if (__popcll(cand) > 1) {                      // (a lone child has no children inside `cand`)
+                u64 c = sg == 0 ? (cand & ~NS) : cand;
+                while (c) {
+                    const int x = __ffsll((long long)c) - 1;
+                    c &= c - 1;
+                    const u64 nc = cand & Hp[x];
+                    if (nc) visit_sg<T + 1, MAXT>(nc, sg != 0 ? sg : (int)cls[x], Hp, cls, NA, NB, NS, delta);
+                }
+            }
+        }
+    }
+}
+__device__ __forceinline__ bool flip_merged_fits(u64 P, u64 MA, u64 MB, u64 S, int k)
+{
+    return __popcll(MA & P) + __popcll(MB & (P | MA)) + __popcll(S & (P | MA | MB)) <= WAVE - k;
+}
+// myH: the raw local masks (in-masks of the build: the evaluator's transposed graph), local indices k, k + 1 = the pair;
+// P, MA, MB, S as classify() gives them for the two directions.  Requires flip_merged_fits().  Returns false -- nothing
+// counted -- if the arc list does not hold the arcs (the caller then runs the two evaluations).  MAXT <= 6, exact depth.
+template <int MAXT>
+__device__ __forceinline__ bool eval_flip_merged(u64 myH, u64 *Hp, u64 P, u64 MA, u64 MB, u64 S, int k, int lane, int (&delta)[MAXT + 1], EvScal &es)
+{
+    const u64 uv = 3ull << k;
+    const u64 xa = MA & P, xb = MB & (P | MA), xs = S & (P | MA | MB);     // vertices that need a further node in MA / MB / S
+    u64 NA = MA & ~P, NB = MB & ~(P | MA), NS = S & ~(P | MA | MB);
+    u32 blo = (u32)myH & ~(u32)uv, bhi = (u32)(myH >> 32) & ~(u32)(uv >> 32);
+    int r = 0;
+    for (u64 m = xa; m; m &= m - 1, ++r) {
+        const u64 ho = rdlane64(myH, __ffsll((long long)m) - 1) & ~uv;
+        blo = wrlane((u32)ho, k + r, blo); bhi = wrlane((u32)(ho >> 32), k + r, bhi);
+        NA |= 1ull << (k + r);
+    }
+    for (u64 m = xb; m; m &= m - 1, ++r) {
+        const u64 ho = rdlane64(myH, __ffsll((long long)m) - 1) & ~uv;
+        blo = wrlane((u32)ho, k + r, blo); bhi = wrlane((u32)(ho >> 32), k + r, bhi);
+        NB |= 1ull << (k + r);
+    }
+    for (u64 m = xs; m; m &= m - 1, ++r) {
+        const u64 ho = rdlane64(myH, __ffsll((long long)m) - 1) & ~uv;
+        blo = wrlane((u32)ho, k + r, blo); bhi = wrlane((u32)(ho >> 32), k + r, bhi);
+        NS |= 1ull << (k + r);
+    }
+    const u64 gprim = P | MA | MB | S;
+    u32 rlo = blo & (u32)gprim, rhi = bhi & (u32)(gprim >> 32);
+    r = 0;
+    for (u64 m = xa; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, k + r);
+    for (u64 m = xb; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, k + r);
+    for (u64 m = xs; m; m &= m - 1, ++r) seat_bit(blo, bhi, rlo, rhi, __ffsll((long long)m) - 1, k + r);
+    // children by the parent's class: P -> any node, MA -> MA and S, MB -> MB and S, S -> S; a lane that is no node: none.
+    // The listed arcs (elo, ehi): not P -> S (nothing can follow but S nodes: no middle), none from an S node.  The sign a
+    // node brings (cv) and the tag its list entries carry (bits 6, 7) are set in the same pass.  One exec mask per class, two
+    // or three vector instructions under each (all 64 lanes are active here: the callers' branches are wave-uniform).
+    const u64 GA = NA | NS, GB = NB | NS, G0 = P | GA | NB, GN = ~G0;
+    u32 elo, ehi, cv, base;
+    asm volatile("s_mov_b64 exec, %[mP]\n\t"
+                 "v_and_b32 %[rlo], %[g0l], %[rlo]\n\tv_and_b32 %[rhi], %[g0h], %[rhi]\n\t"
+                 "v_bitop3_b32 %[elo], %[rlo], %[nsl], %[rlo] bitop3:0x30\n\tv_bitop3_b32 %[ehi], %[rhi], %[nsh], %[rhi] bitop3:0x30\n\t"
+                 "v_mov_b32 %[cv], 0\n\tv_mov_b32 %[base], %[lane]\n\t"
+                 "s_mov_b64 exec, %[mA]\n\t"
+                 "v_and_b32 %[rlo], %[gal], %[rlo]\n\tv_and_b32 %[rhi], %[gah], %[rhi]\n\t"
+                 "v_mov_b32 %[elo], %[rlo]\n\tv_mov_b32 %[ehi], %[rhi]\n\tv_mov_b32 %[cv], -1\n\tv_or_b32 %[base], 64, %[lane]\n\t"
+                 "s_mov_b64 exec, %[mB]\n\t"
+                 "v_and_b32 %[rlo], %[gbl], %[rlo]\n\tv_and_b32 %[rhi], %[gbh], %[rhi]\n\t"
+                 "v_mov_b32 %[elo], %[rlo]\n\tv_mov_b32 %[ehi], %[rhi]\n\tv_mov_b32 %[cv], 1\n\tv_or_b32 %[base], 0x80, %[lane]\n\t"
+                 "s_mov_b64 exec, %[mS]\n\t"
+                 "v_and_b32 %[rlo], %[nsl], %[rlo]\n\tv_and_b32 %[rhi], %[nsh], %[rhi]\n\t"
+                 "v_mov_b32 %[elo], 0\n\tv_mov_b32 %[ehi], 0\n\tv_mov_b32 %[cv], 2\n\tv_mov_b32 %[base], %[lane]\n\t"
+                 "s_mov_b64 exec, %[mN]\n\t"
+                 "v_mov_b32 %[rlo], 0\n\tv_mov_b32 %[rhi], 0\n\tv_mov_b32 %[elo], 0\n\tv_mov_b32 %[ehi], 0\n\tv_mov_b32 %[cv], 0\n\tv_mov_b32 %[base], %[lane]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [rlo] "+v"(rlo), [rhi] "+v"(rhi), [elo] "=&v"(elo), [ehi] "=&v"(ehi), [cv] "=&v"(cv), [base] "=&v"(base)
+                 : [mP] "s"(P), [mA] "s"(NA), [mB] "s"(NB), [mS] "s"(NS), [mN] "s"(GN), [g0l] "s"((u32)G0), [g0h] "s"((u32)(G0 >> 32)),
+                   [gal] "s"((u32)GA), [gah] "s"((u32)(GA >> 32)), [gbl] "s"((u32)GB), [gbh] "s"((u32)(GB >> 32)), [nsl] "s"((u32)NS), [nsh] "s"((u32)(NS >> 32)),
+                   [lane] "v"((u32)lane)
+                 : "memory");
+    signed char *cls = (signed char *)(Hp + WAVE) + 2 * FCM_MERGED_CAP;
+    wave_sync();
+    Hp[lane] = (u64)rlo | ((u64)rhi << 32);
+    cls[lane] = (signed char)cv;
+    const int nch = __popc(elo) + __popc(ehi);
+    const int incl = wave_scan_i32(nch);
+    const int tp = __builtin_amdgcn_readlane(incl, 63);
+    if (tp > FCM_MERGED_CAP) { wave_sync(); return false; }
+    es.d1 += __popcll(NB) - __popcll(NA);
+    if (MAXT < 2 || tp == 0) { wave_sync(); return true; }
+    {
+        unsigned short *list = (unsigned short *)(Hp + WAVE) + (incl - nch);
+        for (u32 c = elo; c; c &= c - 1u) *list++ = (unsigned short)(base | ((u32)(__ffs((int)c) - 1) << 8));
+        for (u32 c = ehi; c; c &= c - 1u) *list++ = (unsigned short)(base | ((u32)(__ffs((int)c) + 31) << 8));
+    }
+    wave_sync();
+    const unsigned short *rd = (const unsigned short *)(Hp + WAVE);
+    int d2 = 0;
+    for (int b0 = 0; b0 < tp; b0 += WAVE) {
+        const int pi = b0 + lane;
+        if (pi < tp) {
+            const u32 e = rd[pi];
+            const u32 y = e >> 8;
+            const int sx = (e & 0x40u) ? -1 : ((e & 0x80u) ? 1 : 0);
+            const int sg = sx != 0 ? sx : (int)cls[y];                        // (a P parent lists no S child: cls[y] is -1, 0 or +1 here)
+            d2 += sg;
+            if constexpr (MAXT >= 3) {
+                const u64 nc = Hp[e & 0x3Fu] & Hp[y];
+                if (nc) visit_sg<2, MAXT>(nc, sg, Hp, cls, NA, NB, NS, delta);
+            }
+        }
+    }
+    es.d2 += wave_sum_i32(d2);
+    wave_sync();
+    return true;
+}
+
 // ---- the three evaluations a simple move is made of (fast path) -------------
 // Lv = the local vertex list (K, then big, small: lane k = big, lane k+1 = small),
 // loaded by the caller.  The raw masks stay in registers; Hp = split

@@ -276,6 +276,14 @@ __device__ __forceinline__ bool cq_eval_pair(u64 myH, u64 *Hp, const CqPair &P, 
     cbs.S = csb.S = inB & inS & nbm;
     cbs.M = inS & outB & nbm;
     csb.M = inB & outS & nbm;
+    if constexpr (MAXT <= 6) {
+        // both directions change: the pair is flipped (10 <-> 01; a clique move hands a pair another pair's pattern, never none):
+        // one signed evaluation for the two (eval_flip_merged) -- the direction that goes is the one that is there now
+        if (need_bs && need_sb && (P.o_bs ^ P.o_sb) != 0u) {
+            const u64 MA = P.o_bs ? cbs.M : csb.M, MB = P.o_bs ? csb.M : cbs.M;
+            if (flip_merged_fits(cbs.P, MA, MB, cbs.S, k) && eval_flip_merged<MAXT>(myH, Hp, cbs.P, MA, MB, cbs.S, k, lane, delta, es)) return true;
+        }
+    }
     if ((need_bs && !extras_fit(cbs, s)) || (need_sb && !extras_fit(csb, s))) return false;
 #pragma nounroll
     for (int dir = 0; dir < 2; ++dir) {   // (a loop over one inlined evaluator: the classes differ in M only)

@@ -99,6 +99,9 @@
 #ifndef MW_K_EVLOOP
 #define MW_K_EVLOOP 0
 #endif
+#ifndef MW_MERGED
+#define MW_MERGED 1       // 1: a flip's two evaluations as one signed evaluation (eval_flip_merged, fcm_kernels_common.hpp)
+#endif
 #define MW_NONE 0xFFFFFFFFu
 // state word of a record: (proposal index << 4) | flags | phase.  Phase 0: not there (not staged yet, or being
 // written again by its exact run); 1: staged -- what the proposal changes if it is accepted; 2: decided.
@@ -370,7 +373,10 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     cB.P = cA.P; cB.S = cA.S;   // after the flip P and S are the same sets, M becomes {v->w, w->u}
                     cB.M = (ab ? hk : hk1) & ballot((myH >> iv) & 1ull) & ~(3ull << k);
                     fres = ab ? 1 : 2;
-                    if (extras_fit(cA, k + 2) && extras_fit(cB, k + 2)) { HA = HB = myH; kA = kB = k; nev = 2; }
+                    // a flip's two evaluations as one (eval_flip_merged: the P*S* cliques, which cancel, are never walked); if its
+                    // nodes do not fit 64, the two evaluations one after the other; if theirs do not either, the wide evaluator
+                    if (MW_MERGED && flip_merged_fits(cA.P, cA.M, cB.M, cA.S, k)) { HA = HB = myH; kA = kB = k; nev = 3; }
+                    else if (extras_fit(cA, k + 2) && extras_fit(cB, k + 2)) { HA = HB = myH; kA = kB = k; nev = 2; }
                     else go_wide = true;
                 }
             } else {
@@ -576,14 +582,18 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
         for (int t = 0; t <= MAXT; ++t) delta[t] = 0;
 #endif
         EvScal es = {0, 0};
+        bool merged_done = false;
+        if (MW_MERGED && nev == 3) merged_done = eval_flip_merged<MAXT>(HA, Hp, cA.P, cA.M, cB.M, cA.S, kA, lane, delta, es);
+        if (!merged_done) {
 #if MW_K_EVLOOP
 #pragma nounroll
 #else
 #pragma unroll
 #endif
-        for (int ev = 0; ev < 2; ++ev) {
-            const Cls c = ev ? cB : cA;
-            eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta, es, nullptr, nullptr, &guard);
+            for (int ev = 0; ev < 2; ++ev) {
+                const Cls c = ev ? cB : cA;
+                eval_nodes<MAXT>(ev ? HB : HA, Hp, c, ev ? kB : kA, tmax, ev ? +1 : -1, lane, delta, es, nullptr, nullptr, &guard);
+            }
         }
 #if MW_PROBE == 2   // (instruction-cost probe: a third evaluation whose sign is an opaque 0)
         { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); eval_nodes<MAXT>(HA, Hp, cA, kA, tmax, z, lane, delta, es, nullptr, nullptr, &guard); }
