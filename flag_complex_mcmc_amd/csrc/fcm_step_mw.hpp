@@ -227,6 +227,11 @@ __device__ __forceinline__ u32 mw_lds_addr(const void *p) { return (u32)(size_t)
 // min over the waves of vis[]: every proposal below it is visible to what this wave loads from now on (acquire)
 __device__ __forceinline__ u32 mw_vis_min(const u32 *vis, u32 W, int lane)
 {
+    if (W == 2u) {   // (two entries: one 64-bit read and a min -- no reduction over the lanes)
+        const u64 v2 = __hip_atomic_load((const u64 *)vis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return mw_uni(min((u32)v2, (u32)(v2 >> 32)));
+    }
     u32 v = __hip_atomic_load(&vis[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // every row of 16 lanes reads all of it (entries >= W hold MW_NONE)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     v = min(v, (u32)__builtin_amdgcn_update_dpp((int)MW_NONE, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1

@@ -14,6 +14,9 @@ echo "== bench (full)"; timeout -k 10 400 python bench.py > $OUT/bench.json 2> $
 for K in 1 3 4; do echo "== bench config $K"; timeout -k 10 300 python bench.py --no-cpu-baseline --config $K --steps 8 > $OUT/bench_config$K.json 2> $OUT/bench_config$K.err || exit 1; done
 echo "== bench 256 chains"; timeout -k 10 300 python bench.py --no-cpu-baseline --chains 256 --steps 8 > $OUT/bench_config2_256chains.json 2> $OUT/bench_256.err || exit 1
 echo "== bench default mix"; timeout -k 10 300 python bench.py --no-cpu-baseline --moves default --steps 8 > $OUT/bench_default_mix.json 2> $OUT/bench_default_mix.err || exit 1
+for K in 1 3 4; do   # the reference's default mix on the other configs' shares (numbers, whatever they are: VERDICT r3 Missing #4)
+  timeout -k 10 300 python bench.py --no-cpu-baseline --moves default --config $K --steps 4 > $OUT/bench_default_mix_config$K.json 2> $OUT/bench_default_mix_config$K.err || echo "default mix config $K failed"
+done
 for CH in 2048 1024 256; do   # the cooperative clique-move kernel (W = 2, 4, 8) and, beside it, the one-wave kernel on the same share
   timeout -k 10 300 python bench.py --no-cpu-baseline --moves default --chains $CH --steps 8 > $OUT/bench_default_mix_${CH}chains.json 2> $OUT/bench_default_mix_$CH.err || exit 1
   FCM_CQ=0 timeout -k 10 300 python bench.py --no-cpu-baseline --moves default --chains $CH --steps 8 > $OUT/bench_default_mix_${CH}chains_onewave.json 2> $OUT/bench_default_mix_${CH}o.err || exit 1

@@ -10,5 +10,6 @@ cp $P/pmc_summary.json profiles/${TAG}_configs_pmc.json
 # the kernel-trace summary of the bench command: the newest one that holds the step kernel
 S=$(ls -t $P/stats/*/*_kernel_stats.csv | while read f; do grep -q fcm_step_ $f && { echo $f; break; }; done)
 cp $S profiles/${TAG}_kernel_stats.csv
+[ -f $P/ablation.txt ] && cp $P/ablation.txt profiles/${TAG}_ablation.txt || true
 [ -f $P/mw_stamps_256chains.txt ] && cp $P/mw_stamps_256chains.txt profiles/${TAG}_mw_stamps_256chains.txt || true
 grep -o '"lib_sha16": "[0-9a-f]*"' profiles/pmc_summary.json | sort | uniq -c
