@@ -1163,7 +1163,10 @@ try {
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     uint64_t left = n_proposals;
     while (left > 0) {
-        const uint64_t chunk = std::min<uint64_t>(left, FCM_LAUNCH_CHUNK);
+        // (samplers with clique moves: launches of at most 4096 proposals -- the clique kernels' per-launch tallies are u32 words in LDS
+        //  and a move can add up to 56 pairs x 2 directions x 1022 common neighbours to the sum of k)
+        static_assert(4096ull * 56ull * 2ull * 1024ull < (1ull << 32), "per-launch tallies of the clique kernels fit 32 bits");
+        const uint64_t chunk = std::min<uint64_t>(left, s->clique_moves ? 4096u : FCM_LAUNCH_CHUNK);
         s->params.nprop = chunk;
         int lrc = fcm_launch_step(&s->params, s->maxt_variant, s->clique_moves ? (s->use_cq ? 3 : 1) : (s->info.waves_per_chain >= 2 ? 2 : 0), s->stream);
         if (lrc) return fail(FCM_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
