@@ -73,7 +73,7 @@
 #define MW_K_ZERO 1
 #endif
 #ifndef MW_K_LANE
-#define MW_K_LANE 0
+#define MW_K_LANE 1
 #endif
 #ifndef MW_VEC_MIN
 #define MW_VEC_MIN 4u   // records to check from which the lookup maps pay (fewer: each is looked at exactly)
