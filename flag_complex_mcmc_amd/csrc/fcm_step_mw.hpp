@@ -241,6 +241,18 @@ __device__ __forceinline__ u32 mw_vis_min(const u32 *vis, u32 W, int lane)
     return rdlane(v, 15);
 }
 
+// A kernel argument re-read where it is used: a scalar load from the kernarg segment, no vector instruction.  The kernel has 80
+// SGPRs at 8 waves per SIMD; what is kept in SGPRs across the loop is spilled to VGPR lanes with the s_load tuple it came in, and
+// every use brings the whole tuple back by v_readlane (the list pointer: eight lanes per list load, 12 vector instructions per
+// proposal; round 4, tools/knob_sq.sh).  The rest of the chain's context through a block of its own was measured and dropped
+// (profiles/r04_kctx_block_dropped.diff): what it saves in v_readlane it spends in scalar moves.
+template <int OFF>
+__device__ __forceinline__ u64 mw_karg64()
+{
+    u64 v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"((u64)(size_t)__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF) : "memory");
+    return v;
+}
 struct MwProp;
 // wave-uniform view of the chain
 struct MwChain {
@@ -338,9 +350,12 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     const int move = (int)(rdlane(tv, 0) & 0xFFu);
     const u32 coin = (rdlane(tv, 0) >> 8) & 1u;
     const u64 idx = (u64)rdlane(tv, 2) | ((u64)rdlane(tv, 3) << 32);
-    const u32 U = C.U, stride32 = ROWS128 ? 32u : C.stride32;   // (cache-line rows: a constant, word ids by shifts)
-    const u64 Mtot = (u64)U + C.D;
+    const u32 U = C.U, D = C.D, stride32 = ROWS128 ? 32u : C.stride32;   // (cache-line rows: a constant, word ids by shifts)
     const rsrc_t rr = make_rows_rsrc(C.rows, C.rows_bytes);
+    const u32 *const nbk = EXACT ? C.nb : (const u32 *)mw_karg64<offsetof(FcmStepParams, nb)>();   // (the hot path: re-read, see mw_karg64)
+    const u32 *const dblk = C.dbl;
+    const FcmEdgeEntry *const etabk = C.etab;
+    const u64 Mtot = (u64)U + D;
 
     // what is to be evaluated on the fast path: two (masks, classes, size), signs -1 and +1
     int nev = 0;
@@ -360,13 +375,13 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             const u32 wid_bs = SPARSE ? (u32)idx >> 4 : e1.big * stride32 + (e1.small >> 5), wid_sb = SPARSE ? wid_bs : e1.small * stride32 + (e1.big >> 5);
             const u32 bit_bs = SPARSE ? ((u32)idx & 15u) * 2u : e1.small & 31u, bit_sb = SPARSE ? bit_bs + 1u : e1.big & 31u;
             if (k + 2 <= WAVE) {
-                O.Lv1 = load_list(C.nb, e1.nb_off, k, e1.big, e1.small, lane);
+                O.Lv1 = load_list(nbk, e1.nb_off, k, e1.big, e1.small, lane);
                 snap_point();
 #if MW_PROBE == 1   // (instruction-cost probe, tools/probe_costs.sh: a flip builds its masks twice)
                 u64 myH = mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
                 { u32 z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); u32 Lz = O.Lv1; asm volatile("" : "+v"(Lz)); myH |= mw_build<ROWS128>(rr, stride32, Lz, k + 2, lane) & (u64)z; }
 #else
-                const u64 myH = SPARSE ? mw_build_sparse(rr, C.nb, e1.nb_off, k, (u32)idx, lane) : mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
+                const u64 myH = SPARSE ? mw_build_sparse(rr, nbk, e1.nb_off, k, (u32)idx, lane) : mw_build<ROWS128>(rr, stride32, O.Lv1, k + 2, lane);
 #endif
                 const u64 hk = rdlane64(myH, k), hk1 = rdlane64(myH, k + 1);
                 const u32 ab = (u32)((hk1 >> k) & 1ull), ba = (u32)((hk >> (k + 1)) & 1ull);  // big->small, small->big
@@ -395,7 +410,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                 } else {
                     fres = 0;
                     if (k + 2 > 64 * maxnw && C.xw && k + 2 <= 64 * FCM_XW_MAXNW) {   // 257..1024 local vertices
-                        const int res = xw_flip(C.xw, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
+                        const int res = xw_flip(C.xw, C.rows, stride32, nbk, e1.nb_off, k, e1.big, e1.small, lane, tmax);
                         { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? xw_count(C.xw, lane - 1) : 0ll; O.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                         wave_sync();
                         R.used_wide = 1u;
@@ -404,7 +419,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     } else if (k + 2 <= 64 * maxnw) {
                         const Wide Wd = wide_carve(wide_lds, maxnw);
                         wide_zero_counts(Wd, lane);
-                        const int res = wide_flip(Wd, C.rows, stride32, C.nb, e1.nb_off, k, e1.big, e1.small, lane, tmax);
+                        const int res = wide_flip(Wd, C.rows, stride32, nbk, e1.nb_off, k, e1.big, e1.small, lane, tmax);
                         { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; O.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                         wave_sync();
                         R.used_wide = 1u;
@@ -422,7 +437,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                 R.add_k = (u32)k; R.big_set = k + 2 > 48 ? 1u : 0u;
             }
         }
-    } else if (move == 1 && C.D > 0) {
+    } else if (move == 1 && D > 0) {
         // ---- double_edge_move (src/lib.rs:304-325)
         R.dslot = (u32)idx;
         FcmEdgeEntry e1 = {rdlane(tv, 8), rdlane(tv, 9), rdlane(tv, 10), rdlane(tv, 11)};            // the table's guess of the slot's pair
@@ -431,14 +446,14 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
         const u32 c0v = rdlane(tv, 12);
         const bool c0ok = c0v != MW_NONE && (int)e2.k + 2 <= WAVE;
         u32 Lv2pre = MW_NONE;
-        if (c0ok) Lv2pre = load_list(C.nb, e2.nb_off, (int)e2.k, e2.big, e2.small, lane);
+        if (c0ok) Lv2pre = load_list(nbk, e2.nb_off, (int)e2.k, e2.big, e2.small, lane);
         // ... and the list of the table's guess of the slot's pair (static as well; thrown away if the slot was rewritten)
         u32 Lv1pre = MW_NONE;
-        if ((int)e1.k + 2 <= WAVE) Lv1pre = load_list(C.nb, e1.nb_off, (int)e1.k, e1.big, e1.small, lane);
+        if ((int)e1.k + 2 <= WAVE) Lv1pre = load_list(nbk, e1.nb_off, (int)e1.k, e1.big, e1.small, lane);
         snap_point();
         // mutable state from here on: the slot's live entry first -- requested here, looked at after candidate 0's build, so
         // that its round trip runs beside that build's instead of in front of it (round 4: + 0.6 % with the list above)
-        const u32 ed_v = C.dbl[R.dslot];
+        const u32 ed_v = dblk[R.dslot];
         // single-edge candidates (:308-313): candidates 0 and 1 come from the table; a longer search, or a
         // candidate that needs the wide path, is left to the exact run
         u64 cand = 0ull, cand_next = 0ull;
@@ -463,7 +478,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             }
             if (cand < U) {
                 if (ci > 0) {
-                    const FcmEdgeEntry t = C.etab[cand];
+                    const FcmEdgeEntry t = etabk[cand];
                     e2 = FcmEdgeEntry{mw_uni(t.big), mw_uni(t.small), mw_uni(t.nb_off), mw_uni(t.k)};
                 }
                 const int ck = (int)e2.k;
@@ -472,9 +487,9 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     if (ci == 0) {
                         O.Lv2 = Lv2pre;
                     } else {
-                        O.Lv2 = load_list(C.nb, e2.nb_off, ck, e2.big, e2.small, lane);
+                        O.Lv2 = load_list(nbk, e2.nb_off, ck, e2.big, e2.small, lane);
                     }
-                    HB = SPARSE ? mw_build_sparse(rr, C.nb, e2.nb_off, ck, (u32)cand, lane) : mw_build<ROWS128>(rr, stride32, O.Lv2, ck + 2, lane);
+                    HB = SPARSE ? mw_build_sparse(rr, nbk, e2.nb_off, ck, (u32)cand, lane) : mw_build<ROWS128>(rr, stride32, O.Lv2, ck + 2, lane);
                     f = (u32)(rdlane64(HB, ck + 1) >> ck) & 1u;
                     bwd = (u32)(rdlane64(HB, ck) >> (ck + 1)) & 1u;
                 } else {
@@ -497,7 +512,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
         }
         const u32 ed = mw_uni(ed_v);
         if (ed != rdlane(tv, 1)) {   // the slot was rewritten since the table was filled (rare)
-            const FcmEdgeEntry t = C.etab[ed];
+            const FcmEdgeEntry t = etabk[ed];
             e1 = FcmEdgeEntry{mw_uni(t.big), mw_uni(t.small), mw_uni(t.nb_off), mw_uni(t.k)};
         }
         R.id1 = ed; R.big1 = e1.big; R.small1 = e1.small;
@@ -510,8 +525,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
             bool okd = true;
             if (!go_wide) {
                 if (ed == rdlane(tv, 1)) O.Lv1 = Lv1pre;
-                else O.Lv1 = load_list(C.nb, e1.nb_off, dk, e1.big, e1.small, lane);
-                HA = SPARSE ? mw_build_sparse(rr, C.nb, e1.nb_off, dk, ed, lane) : mw_build<ROWS128>(rr, stride32, O.Lv1, dk + 2, lane);
+                else O.Lv1 = load_list(nbk, e1.nb_off, dk, e1.big, e1.small, lane);
+                HA = SPARSE ? mw_build_sparse(rr, nbk, e1.nb_off, dk, ed, lane) : mw_build<ROWS128>(rr, stride32, O.Lv1, dk + 2, lane);
                 // (1) remove the direction the coin picks from the reciprocal pair
                 const u32 ab = (u32)((rdlane64(HA, dk + 1) >> dk) & 1ull), ba = (u32)((rdlane64(HA, dk) >> (dk + 1)) & 1ull);
                 okd = (ab & ba) != 0u;
@@ -536,8 +551,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                     R.sus |= 1u;
                 } else if (dk + 2 > 64 * maxnw || rk + 2 > 64 * maxnw) {
                     if (C.xw && dk + 2 <= 64 * FCM_XW_MAXNW && rk + 2 <= 64 * FCM_XW_MAXNW) {
-                        okd = xw_del(C.xw, C.rows, stride32, C.nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
-                        xw_add(C.xw, C.rows, stride32, C.nb, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax, true);
+                        okd = xw_del(C.xw, C.rows, stride32, nbk, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
+                        xw_add(C.xw, C.rows, stride32, nbk, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax, true);
                         { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? xw_count(C.xw, lane - 1) : 0ll; O.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                         wave_sync();
                         R.used_wide = 1u;
@@ -547,8 +562,8 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
                 } else {
                     const Wide Wd = wide_carve(wide_lds, maxnw);
                     wide_zero_counts(Wd, lane);
-                    okd = wide_del(Wd, C.rows, stride32, C.nb, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
-                    wide_add(Wd, C.rows, stride32, C.nb, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax);
+                    okd = wide_del(Wd, C.rows, stride32, nbk, e1.nb_off, dk, e1.big, e1.small, coin, lane, tmax);
+                    wide_add(Wd, C.rows, stride32, nbk, e2.nb_off, rk, e2.big, e2.small, rfwd, dfrom, dto, lane, tmax);
                     { const long long wc = (lane >= 2 && lane < 16 && lane - 1 <= tmax) ? Wd.cnt[lane - 1] : 0ll; O.myd = (int)wc; if (ballot(wc != (long long)(int)wc)) R.sus |= 256u; }
                     wave_sync();
                     R.used_wide = 1u;
