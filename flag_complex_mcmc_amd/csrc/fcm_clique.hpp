@@ -316,6 +316,11 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
     CliqueResult res = clique_setup(T, rows, CL, move, w1, x64, step, gchain, k0, k1, lane, sacc, stt);
     if (res.nchg == 0) return res;
     const int npairs = res.npairs;
+#if FCM_NB_KARG
+    const u32 *const nbk = (const u32 *)fcm_karg64<offsetof(FcmStepParams, nb)>();   // (re-read once per move: see fcm_karg64)
+#else
+    const u32 *const nbk = p.nb;
+#endif
     u64 *Hp = smem + WAVE;
     const u32 stride32 = p.stride32;
     // ---- apply one pair at a time, counting each directed change
@@ -337,7 +342,7 @@ __device__ __forceinline__ CliqueResult clique_propose(const FcmStepParams &p, u
         bool done = false;
         const int s = k + 2;
         if (s <= WAVE) {
-            const u32 Lv = load_list(p.nb, off, k, big, small, lane);
+            const u32 Lv = load_list(nbk, off, k, big, small, lane);
             const u64 myH = build_local(rrows, stride32, Lv, s, lane);
             CLQ_STAMP(4);                                              // per pair: list + build
             // in-masks: run on the transposed graph (see build_local)

@@ -861,6 +861,22 @@ __device__ __forceinline__ int add_eval_built(u64 myH, u32 Lv, int k, u32 fwd, u
     return 1;
 }
 
+// A kernel argument re-read where it is used: a scalar load from the kernarg segment, no vector instruction.  The step kernels
+// have 80 SGPRs at 8 waves per SIMD; what is kept in SGPRs across their loops is spilled to VGPR lanes with the s_load tuple it
+// came in, and every use brings the whole tuple back by v_readlane (the list pointer in the multi-wave kernel: eight lanes per list
+// load, 12 vector instructions per proposal; round 4, tools/knob_sq.sh).  The rest of the chain's context through a block of its
+// own was measured and dropped (profiles/r04_kctx_block_dropped.diff): what it saves in v_readlane it spends in scalar moves.
+template <int OFF>
+__device__ __forceinline__ u64 fcm_karg64()
+{
+    u64 v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"((u64)(size_t)__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF) : "memory");
+    return v;
+}
+#ifndef FCM_NB_KARG
+#define FCM_NB_KARG 1   // the one-wave kernel's clique moves take the list pointer that way too (default mix at 4096 chains + 2 %; its simple
+#endif                  // moves and the cooperative kernel: no difference, left as they were)
+
 // local vertex list of an adjacent pair: K, then big, small
 __device__ __forceinline__ u32 load_list(const u32 *nb, u32 off, int k, u32 big, u32 small, int lane)
 {

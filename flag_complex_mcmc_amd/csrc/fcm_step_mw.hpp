@@ -241,18 +241,6 @@ __device__ __forceinline__ u32 mw_vis_min(const u32 *vis, u32 W, int lane)
     return rdlane(v, 15);
 }
 
-// A kernel argument re-read where it is used: a scalar load from the kernarg segment, no vector instruction.  The kernel has 80
-// SGPRs at 8 waves per SIMD; what is kept in SGPRs across the loop is spilled to VGPR lanes with the s_load tuple it came in, and
-// every use brings the whole tuple back by v_readlane (the list pointer: eight lanes per list load, 12 vector instructions per
-// proposal; round 4, tools/knob_sq.sh).  The rest of the chain's context through a block of its own was measured and dropped
-// (profiles/r04_kctx_block_dropped.diff): what it saves in v_readlane it spends in scalar moves.
-template <int OFF>
-__device__ __forceinline__ u64 mw_karg64()
-{
-    u64 v;
-    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"((u64)(size_t)__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF) : "memory");
-    return v;
-}
 struct MwProp;
 // wave-uniform view of the chain
 struct MwChain {
@@ -352,7 +340,7 @@ __device__ __forceinline__ void mw_run(const MwChain &C, u64 *Hp, u64 *wide_lds,
     const u64 idx = (u64)rdlane(tv, 2) | ((u64)rdlane(tv, 3) << 32);
     const u32 U = C.U, D = C.D, stride32 = ROWS128 ? 32u : C.stride32;   // (cache-line rows: a constant, word ids by shifts)
     const rsrc_t rr = make_rows_rsrc(C.rows, C.rows_bytes);
-    const u32 *const nbk = EXACT ? C.nb : (const u32 *)mw_karg64<offsetof(FcmStepParams, nb)>();   // (the hot path: re-read, see mw_karg64)
+    const u32 *const nbk = EXACT ? C.nb : (const u32 *)fcm_karg64<offsetof(FcmStepParams, nb)>();   // (the hot path: re-read, see fcm_karg64)
     const u32 *const dblk = C.dbl;
     const FcmEdgeEntry *const etabk = C.etab;
     const u64 Mtot = (u64)U + D;

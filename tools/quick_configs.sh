@@ -10,3 +10,6 @@ run c4 --config 4
 run c4_1024 --config 4 --chains 1024
 run c4_4096 --config 4 --chains 4096
 run c2_def --config 2 --moves default
+run c2_def2048 --config 2 --moves default --chains 2048
+run c2_def1024 --config 2 --moves default --chains 1024
+run c1_def --config 1 --moves default
