@@ -252,3 +252,39 @@ def test_batched_transitions_refuse_per_chain_and_fall_back(fcm, oracle):
     assert (st == 0).all()
     for c in range(5):
         assert (s.flag_count(c), s.edges(c).tolist()) == before[c], c
+
+
+def test_apply_transition_on_a_dim_cap_sampler_stays_consistent_with_step(fcm, oracle):
+    """A sampler in truncated mode (dim_cap) tracks fewer count entries than the complex has.  The State API still returns the
+    reference's full-length (pre, post) -- compared with the oracle -- while the handle's own flag_count moves only in the
+    tracked entries; the sampler then goes on from that state and its tracked counts still equal a full recount."""
+    n = 60
+    e = fcm.graphs.random_with_p(n, 0.3, seed=5)
+    gg, go, bg, bo = setup_pair(fcm, oracle, n, e)
+    full_len = len(go.flagser_count())
+    cap = 3
+    s = fcm.MCMCSampler(gg, bg, n_chains=2, seed=9, dim_cap=cap)
+    assert s.info["lossless"] == 0 and s.ncounts == cap + 1 < full_len
+    so = oracle.State(go)
+    sg = s.state(1)
+    ue = so.undirected_edges()
+    rng = np.random.default_rng(8)
+    deeper = 0
+    for it in range(40):
+        cur = {(int(a), int(b)) for a, b in so.graph_edges()}
+        single = [(int(a), int(b)) for a, b in ue if ((int(a), int(b)) in cur) != ((int(b), int(a)) in cur)]
+        a, b = single[rng.integers(len(single))]
+        f, t_ = (a, b) if (a, b) in cur else (b, a)
+        ch = [((f, t_), False), ((t_, f), True)]
+        got = sg.apply_transition(fcm.Transition(ch))
+        want = so.apply_transition(ch)
+        assert got == want, (it, got, want)            # the full vectors, whatever the handle tracks
+        deeper += max(len(got[0]), len(got[1])) > s.ncounts
+        assert list(s.flag_count(1))[: s.ncounts] == list(so.flag_count)[: s.ncounts], it
+        ge, oe = s.edges(1), so.graph_edges()
+        assert ge.shape == oe.shape and (ge == oe).all()
+    assert deeper > 0                                   # some neighbourhoods were deeper than the cap: the case the test is for
+    s.step(300)
+    assert (s.stats()["status"] == 0).all()
+    for c in range(2):
+        assert s.graph(c).flagser_count()[: s.ncounts] == list(s.flag_count(c))[: s.ncounts]
