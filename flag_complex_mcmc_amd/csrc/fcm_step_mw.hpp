@@ -72,6 +72,9 @@
 #ifndef MW_K_ZERO
 #define MW_K_ZERO 1
 #endif
+#ifndef MW_K_LANE2
+#define MW_K_LANE2 1
+#endif
 #ifndef MW_K_LANE
 #define MW_K_LANE 1
 #endif
@@ -839,10 +842,13 @@ __device__ __attribute__((noinline)) void mw_fill_table(u64 *smem, u32 wv, u32 q
     wave_sync();
 }
 
-template <int MAXT, bool ROWS128, bool SPARSE = false>
+// WFIX: the waves per chain as a compile-time constant (2: the instantiation the launcher picks for W = 2 -- ring size, LDS map,
+// the stride of the proposal loop and the two-entry `vis` minimum fold into immediates and the out-of-line wait for several
+// records, which W = 2 never needs, is not in the kernel), or 0: W = p.mw_waves at run time.
+template <int MAXT, bool ROWS128, bool SPARSE = false, int WFIX = 0>
 __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 {
-    const u32 W = p.mw_waves;                              // waves per chain: 2, 4, 8 or 16 (blockDim.x / 64)
+    const u32 W = WFIX ? (u32)WFIX : p.mw_waves;           // waves per chain: 2, 4, 8 or 16 (blockDim.x / 64)
     const int lane = threadIdx.x & (WAVE - 1);
     const u32 wv = mw_uni(threadIdx.x >> 6);
     const u32 chain = blockIdx.x;
@@ -947,6 +953,12 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         MW_EV(2, q - snap);
 
         // ---- before the token: everything the decision can have ready.  sv = the staged record (lane i = word i)
+#if MW_K_LANE2
+        // (and another copy for what follows the run: its lane masks -- lane < 14 is the table entry's and the record's alike -- would
+        //  otherwise be kept across the evaluations in spilled SGPR pairs: two v_writelane and two v_readlane instead of one v_cmp)
+        lane = lane_id;
+        asm volatile("" : "+v"(lane));
+#endif
         u32 sv = lane < SR_WORDS ? stage[lane] : 0u;
         u32 w_clr = O.w_clr, w_set = O.w_set;
 
@@ -954,7 +966,7 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
         bool hit = O.need_exact != 0u;
         u32 hitw;                                 // the same as one scalar word (as a lane mask it costs two spilled SGPRs and a select per use)
         const u32 nent = q - snap;                                            // <= 2W - 1
-        if (nent >= MW_VEC_MIN && !(MW_ABL & 16)) {
+        if (WFIX != 2 && nent >= MW_VEC_MIN && !(MW_ABL & 16)) {   // (W = 2: nent <= 3)
             // several records: all at once and as soon as they are staged (out of line, W >= 4)
             hitw = mw_uni(mw_wait_staged(smem, wv, q, snap, O.Lv1, O.Lv2, hit ? 1u : 0u, W, sv));   // (0 / 1, wave-uniform, and said so: what follows branches on it with scalar branches)
         } else {
@@ -1140,10 +1152,10 @@ __device__ __forceinline__ void mw_wave(const FcmStepParams &p, u64 *smem)
 }
 
 // (W is a launch parameter: the block is W x 64 threads.  8 waves per SIMD whatever W is: at most 64 VGPRs.)
-template <int MAXT, bool ROWS128, bool SPARSE = false>
+template <int MAXT, bool ROWS128, bool SPARSE = false, int WFIX = 0>
 __global__ __launch_bounds__(16 * WAVE, MW_MINW) void fcm_step_mw_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];
     if (blockIdx.x >= p.nchains) return;
-    mw_wave<MAXT, ROWS128, SPARSE>(p, smem);
+    mw_wave<MAXT, ROWS128, SPARSE, WFIX>(p, smem);
 }

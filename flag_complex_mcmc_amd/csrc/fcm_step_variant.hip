@@ -41,7 +41,18 @@ extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *
 extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *stream)
 {
     const size_t words = fcm_mw_lds_words(p->maxnw, (int)p->mw_waves);
-    fcm_step_mw_kernel<FCM_MAXT, FCM_PC == 1, FCM_PC == 5><<<dim3(p->nchains), dim3(p->mw_waves * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
+#ifndef MW_WFIX
+#define MW_WFIX 16  // every W (2, 4, 8, 16) runs an instantiation with the wave count folded in (fcm_step_mw.hpp, mw_wave); 2: only W = 2 does; 0: none
+#endif
+#define MW_LAUNCH(WF, WAVES) fcm_step_mw_kernel<FCM_MAXT, FCM_PC == 1, FCM_PC == 5, WF><<<dim3(p->nchains), dim3((WAVES) * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p)
+    if (MW_WFIX >= 2 && p->mw_waves == 2u) MW_LAUNCH(2, 2);
+#if MW_WFIX >= 16
+    else if (p->mw_waves == 4u) MW_LAUNCH(4, 4);
+    else if (p->mw_waves == 8u) MW_LAUNCH(8, 8);
+    else if (p->mw_waves == 16u) MW_LAUNCH(16, 16);
+#endif
+    else MW_LAUNCH(0, p->mw_waves);
+#undef MW_LAUNCH
     return (int)hipGetLastError();
 }
 #else
