@@ -344,12 +344,14 @@ __device__ __forceinline__ void cq_pairs(const MwChain &C, u64 *Hp, const Clique
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MAXT>
+// (WFIX: the waves per chain as a compile-time constant -- 1, 2, 4, 8: the launcher picks the instantiation, as for the multi-wave
+//  kernel -- or 0: from p.mw_waves at run time)
+template <int MAXT, int WFIX = 0>
 __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const u32 wv = mw_uni(threadIdx.x >> 6);
-    const u32 W = p.mw_waves >= 2 ? p.mw_waves : 1u;       // waves of this chain's workgroup (blockDim.x / 64)
+    const u32 wv = WFIX == 1 ? 0u : mw_uni(threadIdx.x >> 6);
+    const u32 W = WFIX ? (u32)WFIX : (p.mw_waves >= 2 ? p.mw_waves : 1u);   // waves of this chain's workgroup (blockDim.x / 64)
     const u32 chain = blockIdx.x;
     const u32 N = (u32)p.nprop;
     if (N == 0) return;
@@ -617,10 +619,10 @@ __device__ __forceinline__ void cq_wave(const FcmStepParams &p, u64 *smem)
 // (W is a launch parameter: the block is W x 64 threads.  4 waves per SIMD: at most 128 VGPRs.  A lean build in 64 VGPRs -- 8
 //  waves per SIMD, W = 2 at 4096 chains -- was built and measured in round 4: 6.6e7 proposals/s against the one-wave kernel's
 //  9.3e7 there; profiles/r04_cq_lean_dropped.diff)
-template <int MAXT>
+template <int MAXT, int WFIX = 0>
 __global__ __launch_bounds__(CQ_MAXW * WAVE, 4) void fcm_step_cq_kernel(const FcmStepParams p)
 {
     extern __shared__ u64 smem[];
     if (blockIdx.x >= p.nchains) return;
-    cq_wave<MAXT>(p, smem);
+    cq_wave<MAXT, WFIX>(p, smem);
 }

@@ -31,7 +31,16 @@ extern "C" int FCM_CAT(fcm_launch_step_, FCM_TAG)(const FcmStepParams *p, void *
 {
     const unsigned W = p->mw_waves >= 2 ? p->mw_waves : 1u;
     const size_t words = fcm_cq_lds_words(p->maxnw < 2 ? 2 : p->maxnw, p->chg_cap, W);
-    fcm_step_cq_kernel<FCM_MAXT><<<dim3(p->nchains), dim3(W * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p);
+#ifndef CQ_WFIX
+#define CQ_WFIX 1   // 1: every W (1, 2, 4, 8) runs an instantiation with the wave count folded in; 0: one kernel, W at run time
+#endif
+#define CQ_LAUNCH(WF) fcm_step_cq_kernel<FCM_MAXT, WF><<<dim3(p->nchains), dim3(W * WAVE), sizeof(u64) * words, (hipStream_t)stream>>>(*p)
+    if (CQ_WFIX && W == 1u) CQ_LAUNCH(1);
+    else if (CQ_WFIX && W == 2u) CQ_LAUNCH(2);
+    else if (CQ_WFIX && W == 4u) CQ_LAUNCH(4);
+    else if (CQ_WFIX && W == 8u) CQ_LAUNCH(8);
+    else CQ_LAUNCH(0);
+#undef CQ_LAUNCH
     return (int)hipGetLastError();
 }
 #elif defined(FCM_PC) && FCM_PC
