@@ -168,6 +168,9 @@ __device__ __forceinline__ u64 fcm_stamp()
 // simplices through v->u (same sets, orders reversed, classes P and S
 // swapped).  Callers therefore hand classify() the endpoints the other way
 // round, and read "x -> y is present" as bit x of the mask of y.
+#ifndef FCM_BUILD_GROUP4
+#define FCM_BUILD_GROUP4 1
+#endif
 #ifndef FCM_HB
 #define FCM_HB 24  // rows in flight per batch (16: -2%, 32: -4% on config 3)
 #endif
@@ -184,6 +187,23 @@ __device__ __forceinline__ rsrc_t make_rows_rsrc(const u32 *rows, u64 bytes)
 template <int I0, int N, bool GUARDED>
 __device__ __forceinline__ void build_issue(const rsrc_t rsrc, u32 voff, u32 roff, int s, u32 (&w)[N])
 {
+#if FCM_BUILD_GROUP4
+    if constexpr (!GUARDED && N % 4 == 0) {
+        // four row offsets first, then the four loads: a load whose soffset was written by v_readlane right before it waits five
+        // cycles for the SGPR (s_nop 4 per row); behind three more v_readlane it does not (round 4: default mix + 1 %.  The same
+        // for the guarded tiers, a test per group of four, spills vector registers and is 10 % slower: not done)
+#pragma unroll
+        for (int g = 0; g < N; g += 4) {
+            u32 o0 = rdlane(roff, I0 + g), o1 = rdlane(roff, I0 + g + 1), o2 = rdlane(roff, I0 + g + 2), o3 = rdlane(roff, I0 + g + 3);
+            asm volatile("" : "+s"(o0), "+s"(o1), "+s"(o2), "+s"(o3));
+            w[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, o0, 0);
+            w[g + 1] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, o1, 0);
+            w[g + 2] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, o2, 0);
+            w[g + 3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, o3, 0);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         w[q] = 0u;
